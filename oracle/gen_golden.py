@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference planners (build container only).
+
+Test infrastructure: imports the reference classes through oracle/ref_loader.py
+(definitions only, no driver code), seeds CPython's `random` explicitly, runs
+`planning(animation=False)` and stores inputs + outputs as .npz under
+tests/golden/.  Only data is stored (final SoA tree, returned path, a compact
+per-iteration trace); no reference source text enters the repo.
+
+Environment of the goldens (part of the fixture): CPython 3.10.12,
+numpy 2.2.6, glibc 2.35 (x86-64 FMA ifunc variants), this container's Xeon.
+
+Usage: python oracle/gen_golden.py [--only PREFIX] [--big]
+"""
+import argparse
+import contextlib
+import io
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_loader  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+DRIVER_OBST = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)]
+
+
+def synth_map(map_seed, m, rmin=0.5, rmax=2.5):
+    """SURVEY.md 8(d) / section 10 map generator (private Random, independent of the planner stream)."""
+    rng = random.Random(map_seed)
+    obs = []
+    while len(obs) < m:
+        x = rng.uniform(0, 100)
+        y = rng.uniform(0, 100)
+        r = rng.uniform(rmin, rmax)
+        ok = True
+        for (kx, ky) in ((2, 2), (98, 98)):
+            if not ((x - kx) ** 2 + (y - ky) ** 2 > (r + 3) ** 2):
+                ok = False
+        if ok:
+            obs.append((x, y, r))
+    return obs
+
+
+def tree_arrays(node_list, int_parent=False):
+    n = len(node_list)
+    x = np.array([float(nd.x) for nd in node_list], dtype=np.float64)
+    y = np.array([float(nd.y) for nd in node_list], dtype=np.float64)
+    cost = np.array([float(nd.cost) for nd in node_list], dtype=np.float64) if hasattr(node_list[0], "cost") \
+        else np.zeros(n)
+    if int_parent:
+        parent = np.array([-1 if nd.parent is None else int(nd.parent) for nd in node_list], dtype=np.int32)
+    else:
+        ids = {id(nd): i for i, nd in enumerate(node_list)}
+        parent = np.array([-1 if nd.parent is None else ids.get(id(nd.parent), -2) for nd in node_list],
+                          dtype=np.int32)
+    return x, y, cost, parent
+
+
+def run_rrt04(mod, name, obstacles, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
+              play_area, robot_radius, sobol, ccd, until_max, seed, trace=True, algo="rrt_star"):
+    ref_loader.reset_sobol(mod)
+    random.seed(seed)
+    kw = dict(start=start, goal=goal, obstacle_list=obstacles, rand_area=rand_area, expand_dis=expand_dis,
+              path_resolution=path_resolution, goal_sample_rate=goal_sample_rate, max_iter=max_iter,
+              play_area=play_area, robot_radius=robot_radius)
+    if algo == "rrt_star":
+        kw.update(sobol_sampler=sobol, connect_circle_dist=ccd, search_until_max_iter=until_max)
+    rrt = mod.RRT(**kw)
+    tr = {"rnd_x": [], "rnd_y": [], "nearest": [], "n_near": [], "n_nodes": []}
+    edges = [0]
+    if trace:
+        cls = mod.RRT
+        o_near = cls.get_nearest_node_index
+        o_cc = cls.check_collision
+
+        def near_hook(node_list, rnd):
+            i = o_near(node_list, rnd)
+            tr["rnd_x"].append(float(rnd.x))
+            tr["rnd_y"].append(float(rnd.y))
+            tr["nearest"].append(i)
+            tr["n_nodes"].append(len(node_list))
+            return i
+
+        def cc_hook(node, ol, rr):
+            edges[0] += 1
+            return o_cc(node, ol, rr)
+        rrt.get_nearest_node_index = near_hook
+        rrt.check_collision = cc_hook
+        if algo == "rrt_star":
+            o_fn = rrt.find_near_nodes
+
+            def fn_hook(new_node):
+                r = o_fn(new_node)
+                tr["n_near"].append(len(r))
+                return r
+            rrt.find_near_nodes = fn_hook
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = rrt.planning(animation=False)
+    dt = time.time() - t0
+    x, y, cost, parent = tree_arrays(rrt.node_list)
+    assert (parent != -2).all(), "stale parent object"
+    state = random.getstate()
+    out = dict(
+        algo=algo, seed=seed, obstacles=np.array(obstacles, dtype=np.float64), start=np.array(start, dtype=np.float64),
+        goal=np.array(goal, dtype=np.float64), rand_area=np.array(rand_area, dtype=np.float64),
+        expand_dis=expand_dis, path_resolution=path_resolution, goal_sample_rate=goal_sample_rate,
+        max_iter=max_iter, play_area=np.array(play_area if play_area is not None else [], dtype=np.float64),
+        robot_radius=robot_radius, sobol=int(bool(sobol)), connect_circle_dist=ccd, until_max=int(bool(until_max)),
+        x=x, y=y, cost=cost, parent=parent,
+        path=np.array(path if path is not None else [], dtype=np.float64).reshape(-1, 2),
+        path_found=int(path is not None), ref_seconds=dt, ref_edges=edges[0],
+        rng_pos_after=state[1][624], rng_word0_after=np.uint32(state[1][0]),
+        sobol_index_after=getattr(rrt, "sobol_inter_", 0),
+        tr_rnd_x=np.array(tr["rnd_x"]), tr_rnd_y=np.array(tr["rnd_y"]),
+        tr_nearest=np.array(tr["nearest"], dtype=np.int32), tr_n_near=np.array(tr["n_near"], dtype=np.int32),
+        tr_n_nodes=np.array(tr["n_nodes"], dtype=np.int32),
+    )
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-28s nodes=%d path=%s edges=%d  %.2fs" % (name, len(x), None if path is None else len(path), edges[0], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--big", action="store_true", help="also the 8000-iteration C2 case (~80 s)")
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+
+    def want(n):
+        return n.startswith(a.only)
+
+    m04 = ref_loader.load("rrt_04")
+    m01 = ref_loader.load("rrt_01")
+    drv = dict(obstacles=DRIVER_OBST, start=[0, 0], goal=[6.0, 10.0], rand_area=[-2, 15], expand_dis=1.0,
+               path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=[0, 10, 0, 14], robot_radius=0.6,
+               ccd=50.0)
+    # rrt_04 driver scenario (rrt_04:1498-1546)
+    for seed in (1234, 5, 42):
+        for sob in (0, 1):
+            n = "rrt04_drv_%s_s%d" % ("sobol" if sob else "mt", seed)
+            if want(n):
+                run_rrt04(m04, n, sobol=sob, until_max=True, seed=seed, **drv)
+    for seed in (1, 2, 3, 7):
+        n = "rrt04_drv_early_s%d" % seed
+        if want(n):
+            run_rrt04(m04, n, sobol=0, until_max=False, seed=seed, **drv)
+    n = "rrt04_drv_noplay_s9"
+    if want(n):
+        d2 = dict(drv)
+        d2["play_area"] = None
+        d2["max_iter"] = 1500
+        run_rrt04(m04, n, sobol=0, until_max=True, seed=9, **d2)
+    n = "rrt04_drv_long_s5"
+    if want(n):
+        d2 = dict(drv)
+        d2["max_iter"] = 1500
+        run_rrt04(m04, n, sobol=0, until_max=True, seed=5, **d2)
+    # C2-style synthetic map
+    c2 = dict(obstacles=synth_map(7, 50), start=[2, 2], goal=[98, 98], rand_area=[0, 100], expand_dis=2.0,
+              path_resolution=0.25, goal_sample_rate=5, play_area=None, robot_radius=0.0, ccd=50.0)
+    for it in (1000, 2000, 4000) + ((8000,) if a.big else ()):
+        n = "rrt04_c2_s1_it%d" % it
+        if want(n):
+            run_rrt04(m04, n, sobol=0, until_max=True, seed=1, max_iter=it, **c2)
+    for seed in (2, 3):
+        n = "rrt04_c2_s%d_it1500" % seed
+        if want(n):
+            run_rrt04(m04, n, sobol=0, until_max=True, seed=seed, max_iter=1500, **c2)
+    n = "rrt04_c2_sobol_s4_it1500"
+    if want(n):
+        run_rrt04(m04, n, sobol=1, until_max=True, seed=4, max_iter=1500, **c2)
+    # rrt_01 driver scenario (rrt_01:354-391), seeds 0..15 (config C1)
+    d1 = dict(drv)
+    d1["play_area"] = None
+    for seed in list(range(16)) + [42]:
+        n = "rrt01_drv_s%d" % seed
+        if want(n):
+            run_rrt04(m01, n, sobol=0, until_max=False, seed=seed, algo="rrt", **d1)
+
+
+if __name__ == "__main__":
+    main()

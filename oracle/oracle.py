@@ -1,0 +1,124 @@
+"""ctypes wrapper of the CPU oracle (oracle/rrt_oracle.c) -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Params(C.Structure):
+    _fields_ = [("algo", C.c_int32), ("goal_sample_rate", C.c_int32), ("max_iter", C.c_int32),
+                ("has_play_area", C.c_int32), ("sobol", C.c_int32), ("search_until_max_iter", C.c_int32),
+                ("exact_pow", C.c_int32), ("pad_", C.c_int32),
+                ("start", C.c_double * 2), ("goal", C.c_double * 2),
+                ("rand_min", C.c_double), ("rand_max", C.c_double),
+                ("expand_dis", C.c_double), ("path_resolution", C.c_double),
+                ("play_area", C.c_double * 4), ("robot_radius", C.c_double),
+                ("connect_circle_dist", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("edges_ref", "edges_unique", "near_hits", "near_unique", "rewires",
+                                         "propagated", "iterations", "scan_nodes", "pow_slow", "sobol_index")]
+
+
+class MT(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("pos", C.c_int32)]
+
+
+class Out(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("cost", C.c_void_p), ("parent", C.c_void_p),
+                ("cap", C.c_int32), ("n", C.c_int32),
+                ("path_xy", C.c_void_p), ("path_cap", C.c_int32), ("path_n", C.c_int32),
+                ("tr_rnd_x", C.c_void_p), ("tr_rnd_y", C.c_void_p), ("tr_nearest", C.c_void_p),
+                ("tr_n_near", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32)]
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "rrt_oracle.c")):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.orc_plan.restype = C.c_int
+        _LIB.orc_hypot.restype = C.c_double
+        _LIB.orc_hypot.argtypes = [C.c_double, C.c_double]
+    return _LIB
+
+
+def mt_from_seed(seed):
+    s = MT()
+    lib().orc_mt_seed(C.byref(s), C.c_uint64(abs(int(seed))))
+    return s
+
+
+def mt_from_pystate(state):
+    """state = random.getstate()"""
+    s = MT()
+    for i in range(624):
+        s.mt[i] = state[1][i]
+    s.pos = state[1][624]
+    return s
+
+
+def plan(algo="rrt_star", start=(0, 0), goal=(6, 10), obstacles=(), rand_area=(-2, 15), expand_dis=3.0,
+         path_resolution=0.5, goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol=False,
+         connect_circle_dist=50.0, search_until_max_iter=False, seed=None, rng=None, exact_pow=True, trace=False):
+    """Run one planning() call on the oracle; returns dict(x,y,cost,parent,path,stats,rng,trace...)."""
+    L = lib()
+    p = Params()
+    p.algo = {"rrt": 0, "rrt_star": 1}[algo]
+    p.goal_sample_rate = int(goal_sample_rate)
+    p.max_iter = int(max_iter)
+    p.has_play_area = 0 if play_area is None or len(play_area) == 0 else 1
+    p.sobol = int(bool(sobol))
+    p.search_until_max_iter = int(bool(search_until_max_iter))
+    p.exact_pow = int(bool(exact_pow))
+    p.start[0], p.start[1] = float(start[0]), float(start[1])
+    p.goal[0], p.goal[1] = float(goal[0]), float(goal[1])
+    p.rand_min, p.rand_max = float(rand_area[0]), float(rand_area[1])
+    p.expand_dis, p.path_resolution = float(expand_dis), float(path_resolution)
+    if p.has_play_area:
+        for i in range(4):
+            p.play_area[i] = float(play_area[i])
+    p.robot_radius = float(robot_radius)
+    p.connect_circle_dist = float(connect_circle_dist)
+    obst = np.ascontiguousarray(np.array(obstacles, dtype=np.float64).reshape(-1, 3))
+    if rng is None:
+        rng = mt_from_seed(seed)
+    cap = int(max_iter) + 2
+    x = np.zeros(cap); y = np.zeros(cap); cost = np.zeros(cap); parent = np.zeros(cap, dtype=np.int32)
+    path = np.zeros((cap + 2, 2))
+    o = Out()
+    o.x, o.y, o.cost, o.parent = x.ctypes.data, y.ctypes.data, cost.ctypes.data, parent.ctypes.data
+    o.cap = cap
+    o.path_xy, o.path_cap = path.ctypes.data, cap + 2
+    if trace:
+        trx = np.zeros(max_iter); try_ = np.zeros(max_iter)
+        trn = np.zeros(max_iter, dtype=np.int32); trk = np.zeros(max_iter, dtype=np.int32)
+        o.tr_rnd_x, o.tr_rnd_y, o.tr_nearest, o.tr_n_near = trx.ctypes.data, try_.ctypes.data, trn.ctypes.data, trk.ctypes.data
+        o.tr_cap = int(max_iter)
+    st = Stats()
+    rc = L.orc_plan(C.byref(p), obst.ctypes.data_as(C.c_void_p), C.c_int(len(obst)), C.byref(rng), C.byref(o),
+                    C.byref(st))
+    if rc != 0:
+        raise RuntimeError("orc_plan failed: %d" % rc)
+    n = o.n
+    res = dict(x=x[:n].copy(), y=y[:n].copy(), cost=cost[:n].copy(), parent=parent[:n].copy(),
+               path=path[:o.path_n].copy() if o.path_n else None,
+               stats={k: getattr(st, k) for k, _ in Stats._fields_}, rng=rng)
+    if trace:
+        t = o.tr_n
+        res.update(tr_rnd_x=trx[:t].copy(), tr_rnd_y=try_[:t].copy(), tr_nearest=trn[:t].copy(), tr_n_near=trk[:t].copy())
+    return res

@@ -1,0 +1,638 @@
+#!/usr/bin/env python3
+"""Generate bit-exact replicas of the glibc libm entry points CPython's `math`
+module (and float `**`) resolves to on this image, as portable C that gcc and
+hipcc both compile.
+
+Why this exists
+---------------
+The reference planners (rrt_04:1100-1101, 1198, 1236-1237, ...) take every
+branch through `math.cos/sin/atan2` and float `x**2`, i.e. through glibc 2.35's
+x86-64 *FMA ifunc variants* (`__sin_fma`, `__cos_fma`, `__ieee754_atan2_fma`,
+`__pow_fma`).  Those are < 1 ULP but NOT correctly rounded, and the RRT* loop
+contains constructed near-ties (an 8x0.25 extension compared with 2.0, a near
+ball of radius exactly expand_dis) where one ULP decides an integer parent
+index.  A GPU cannot call glibc, so integer parity needs the same roundings.
+
+glibc's sources are not in the image (no network), and the FMA variants are the
+generic C files compiled with `-mfma -mavx2` under GCC's default
+-ffp-contract=fast, so which multiply-adds are fused is a property of the
+shipped binary, not of the published source.  This tool therefore restates the
+four functions *operation by operation from the installed libm.so.6*: it walks
+the scalar-double instruction stream of each function (objdump -d), and emits
+one C statement per instruction (IEEE add/sub/mul/div/fma, bit ops, compares,
+table loads), with the constant tables copied as data.  Rounding-mode
+save/restore (MXCSR) is dropped: callers run in round-to-nearest.
+
+Branches that leave the restated domain (huge-argument reduction `__branred`,
+overflow/underflow error exits of pow) return NaN and raise the `ood` flag.
+
+Output: one header with `static inline double rpp_glibc_{sin,cos,atan2,pow}`.
+Verified against the live libm by tests/test_glibc_math.py.
+
+Usage: python tools/lift_libm.py [--libm PATH] [--out HEADER]
+"""
+import argparse
+import hashlib
+import re
+import struct
+import subprocess
+import sys
+
+FUNCS = [
+    # name, entry, end(exclusive), args
+    ("pow", 0x768b0, 0x76ee0, 2),
+    ("atan2", 0x78060, 0x789b0, 2),
+    ("sin", 0x789b0, 0x791c0, 1),
+    ("cos", 0x791c0, 0x799d0, 1),
+]
+EXPECT_SHA256 = None  # filled by --print-sha; checked when not None
+
+GPR64 = ["rax", "rbx", "rcx", "rdx", "rsi", "rdi", "rbp", "rsp"] + ["r%d" % i for i in range(8, 16)]
+REGMAP = {}
+for r in ["rax", "rbx", "rcx", "rdx"]:
+    l = r[1]
+    REGMAP[r] = (r, 64, 0)
+    REGMAP["e" + l + "x"] = (r, 32, 0)
+    REGMAP[l + "x"] = (r, 16, 0)
+    REGMAP[l + "l"] = (r, 8, 0)
+    REGMAP[l + "h"] = (r, 8, 8)
+for r in ["rsi", "rdi", "rbp", "rsp"]:
+    REGMAP[r] = (r, 64, 0)
+    REGMAP["e" + r[1:]] = (r, 32, 0)
+    REGMAP[r[1:]] = (r, 16, 0)
+    REGMAP[r[1:] + "l"] = (r, 8, 0)
+for i in range(8, 16):
+    r = "r%d" % i
+    REGMAP[r] = (r, 64, 0)
+    REGMAP[r + "d"] = (r, 32, 0)
+    REGMAP[r + "w"] = (r, 16, 0)
+    REGMAP[r + "b"] = (r, 8, 0)
+
+UT = {8: "uint8_t", 16: "uint16_t", 32: "uint32_t", 64: "uint64_t"}
+ST = {8: "int8_t", 16: "int16_t", 32: "int32_t", 64: "int64_t"}
+
+
+class Lifter:
+    def __init__(self, libm):
+        self.libm = libm
+        self.blob = open(libm, "rb").read()
+        dis = subprocess.run(["objdump", "-d", "--no-show-raw-insn", libm],
+                             capture_output=True, text=True, check=True).stdout
+        self.ins = {}
+        order = []
+        for l in dis.split("\n"):
+            m = re.match(r"^\s*([0-9a-f]+):\t(.*)$", l)
+            if m:
+                a = int(m.group(1), 16)
+                self.ins[a] = m.group(2).strip()
+                order.append(a)
+        self.nxt = {order[i]: order[i + 1] for i in range(len(order) - 1)}
+        # .rodata: vaddr == file offset on this build (checked)
+        sec = subprocess.run(["readelf", "-S", "-W", libm], capture_output=True, text=True, check=True).stdout
+        m = re.search(r"\.rodata\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", sec)
+        self.ro_va, self.ro_off, self.ro_sz = (int(x, 16) for x in m.groups())
+        self.tables = {}  # base vaddr -> max offset seen (bytes)
+
+    def rd64(self, va):
+        off = va - self.ro_va + self.ro_off
+        assert self.ro_va <= va < self.ro_va + self.ro_sz, hex(va)
+        return struct.unpack_from("<Q", self.blob, off)[0]
+
+    def rd32(self, va):
+        off = va - self.ro_va + self.ro_off
+        return struct.unpack_from("<I", self.blob, off)[0]
+
+    # ---------------- operand parsing -----------------
+    @staticmethod
+    def split_ops(s):
+        out, depth, cur = [], 0, ""
+        for ch in s:
+            if ch == "(":
+                depth += 1
+            if ch == ")":
+                depth -= 1
+            if ch == "," and depth == 0:
+                out.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            out.append(cur.strip())
+        return out
+
+    def parse(self, addr):
+        t = self.ins[addr]
+        t = re.sub(r"\s*#.*$", "", t)
+        t = re.sub(r"\s*<[^>]*>", "", t)
+        parts = t.split(None, 1)
+        mn = parts[0]
+        ops = self.split_ops(parts[1]) if len(parts) > 1 else []
+        return mn, ops
+
+    def mem(self, op, addr):
+        """returns ('abs', va) | ('stk', off) | ('dyn', c_expr_of_address) | ('fs',)"""
+        if op.startswith("%fs:"):
+            return ("fs",)
+        m = re.match(r"^(-?0x[0-9a-f]+|-?\d+)?\((%\w+)?(?:,(%\w+),(\d))?\)$", op)
+        assert m, op
+        disp = int(m.group(1), 0) if m.group(1) else 0
+        base, idx, sc = m.group(2), m.group(3), m.group(4)
+        if base == "%rip":
+            return ("abs", self.nxt[addr] + disp)
+        if base == "%rsp" and idx is None:
+            return ("stk", disp)
+        e = []
+        if base:
+            e.append(self.rreg(base[1:], 64))
+        if idx:
+            e.append("(%s*%sULL)" % (self.rreg(idx[1:], 64), sc))
+        if disp:
+            e.append("(uint64_t)(int64_t)(%d)" % disp)
+        return ("dyn", "(" + "+".join(e) + ")")
+
+    # ---------------- register access -----------------
+    def rreg(self, name, want=None):
+        r, w, sh = REGMAP[name]
+        if w == 64:
+            return r
+        if sh:
+            return "((%s)(%s>>8))" % (UT[8], r)
+        return "((%s)%s)" % (UT[w], r)
+
+    def wreg(self, name, val):
+        r, w, sh = REGMAP[name]
+        if w == 64:
+            return "%s = (uint64_t)(%s);" % (r, val)
+        if w == 32:
+            return "%s = (uint64_t)(uint32_t)(%s);" % (r, val)
+        if sh:
+            return "%s = (%s & ~0xff00ULL) | ((uint64_t)(uint8_t)(%s) << 8);" % (r, r, val)
+        mask = (1 << w) - 1
+        return "%s = (%s & ~0x%xULL) | (uint64_t)(%s)(%s);" % (r, r, mask, UT[w], val)
+
+    def regw(self, name):
+        return REGMAP[name][1]
+
+    # integer operand read with width w
+    def iread(self, op, w, addr):
+        if op.startswith("$"):
+            v = int(op[1:], 0)
+            return "((%s)%dLL)" % (UT[w], v) if v < 0 else "((%s)0x%xULL)" % (UT[w], v)
+        if op.startswith("%") and not op.startswith("%fs"):
+            return self.rreg(op[1:])
+        k = self.mem(op, addr)
+        if k[0] == "fs":
+            return "((%s)0)" % UT[w]
+        if k[0] == "abs":
+            if not (self.ro_va <= k[1] < self.ro_va + self.ro_sz):
+                return "((%s)0) /* GOT/TLS slot: errno plumbing, dropped */" % UT[w]
+            v = self.rd64(k[1]) if w == 64 else self.rd32(k[1])
+            return "((%s)0x%xULL)" % (UT[w], v)
+        if k[0] == "stk":
+            return "((%s)STK%d(%d))" % (UT[w], w, k[1])
+        return "((%s)ROM%d(%s))" % (UT[w], w, k[1])
+
+    def iwrite(self, op, w, val, addr):
+        if op.startswith("%") and not op.startswith("%fs"):
+            return self.wreg(op[1:], val)
+        k = self.mem(op, addr)
+        if k[0] == "fs":
+            return "/* errno store dropped */"
+        assert k[0] == "stk", (hex(addr), op)
+        return "SETSTK%d(%d, %s);" % (w, k[1], val)
+
+    # xmm low-64 read as bits
+    def xread(self, op, addr):
+        if op.startswith("%xmm"):
+            return "x%s" % op[4:]
+        k = self.mem(op, addr)
+        if k[0] == "abs":
+            return "0x%016xULL" % self.rd64(k[1])
+        if k[0] == "stk":
+            return "STK64(%d)" % k[1]
+        return "ROM64(%s)" % k[1]
+
+    def xread32(self, op, addr):
+        if op.startswith("%xmm"):
+            return "((uint32_t)x%s)" % op[4:]
+        k = self.mem(op, addr)
+        if k[0] == "abs":
+            return "0x%08xU" % self.rd32(k[1])
+        if k[0] == "stk":
+            return "STK32(%d)" % k[1]
+        return "ROM32(%s)" % k[1]
+
+    def width_of(self, mn, ops):
+        for o in reversed(ops):
+            if o.startswith("%") and not o.startswith("%xmm") and not o.startswith("%fs"):
+                return self.regw(o[1:])
+        if mn.endswith("q"):
+            return 64
+        if mn.endswith("l"):
+            return 32
+        if mn.endswith("b"):
+            return 8
+        raise ValueError((mn, ops))
+
+    # ---------------- one instruction -----------------
+    def flags_logic(self, w, res):
+        return ("zf = ((%s)(%s) == 0); sf = ((%s)(%s) < 0); cf = 0; of = 0;"
+                % (UT[w], res, ST[w], res))
+
+    def emit(self, addr, region):
+        mn, ops = self.parse(addr)
+        D = lambda b: "D(%s)" % b
+        out = []
+        o = out.append
+
+        def X(i):
+            return self.xread(ops[i], addr)
+
+        def dstx():
+            return "x%s" % ops[-1][4:]
+
+        lo, hi = region
+        if mn in ("endbr64", "nop", "nopl", "nopw", "cs", "push", "pop", "vldmxcsr", "ldmxcsr", "vzeroupper"):
+            return ["/* %s */" % mn]
+        if mn in ("vstmxcsr", "stmxcsr"):
+            k = self.mem(ops[0], addr)
+            assert k[0] == "stk"
+            return ["SETSTK32(%d, 0x1f80u);" % k[1]]
+        if mn == "ret":
+            return ["return D(x0);"]
+        if mn == "call":
+            return ["*ood = 1; return D(0x7ff8000000000000ULL); /* %s */" % self.ins[addr]]
+        if mn == "jmp":
+            tgt = int(ops[0], 16)
+            if not (lo <= tgt < hi):
+                return ["*ood = 1; return D(0x7ff8000000000000ULL); /* tail call %x */" % tgt]
+            return ["goto L%x;" % tgt]
+        if mn.startswith("j"):
+            cc = mn[1:]
+            tgt = int(ops[0], 16)
+            cond = self.cond(cc)
+            if not (lo <= tgt < hi):
+                return ["if (%s) { *ood = 1; return D(0x7ff8000000000000ULL); }" % cond]
+            return ["if (%s) goto L%x;" % (cond, tgt)]
+        if mn.startswith("cmov"):
+            w = self.width_of(mn, ops)
+            return ["if (%s) { %s }" % (self.cond(mn[4:]), self.wreg(ops[1][1:], self.iread(ops[0], w, addr)))]
+        if mn.startswith("set"):
+            return [self.wreg(ops[0][1:], "(%s) ? 1 : 0" % self.cond(mn[3:]))]
+
+        # ---- scalar double arithmetic
+        if mn in ("vaddsd", "vsubsd", "vmulsd", "vdivsd"):
+            c = {"vaddsd": "+", "vsubsd": "-", "vmulsd": "*", "vdivsd": "/"}[mn]
+            return ["%s = B(%s %s %s);" % (dstx(), D(X(1)), c, D(X(0)))]
+        if mn in ("addsd", "subsd", "mulsd", "divsd"):
+            c = {"addsd": "+", "subsd": "-", "mulsd": "*", "divsd": "/"}[mn]
+            return ["%s = B(%s %s %s);" % (dstx(), D(X(1)), c, D(X(0)))]
+        if mn in ("addss", "subss", "mulss", "divss"):
+            c = {"addss": "+", "subss": "-", "mulss": "*", "divss": "/"}[mn]
+            return ["%s = (%s & ~0xffffffffULL) | BF(F(%s) %s F(%s));"
+                    % (dstx(), dstx(), "(uint32_t)" + dstx(), c, self.xread32(ops[0], addr))]
+        m = re.match(r"^vf(n?)m(add|sub)(132|213|231)sd$", mn)
+        if m:
+            neg, addsub, order = m.groups()
+            a, b, d = X(0), X(1), dstx()
+            if order == "132":
+                m1, m2, ad = d, a, b
+            elif order == "213":
+                m1, m2, ad = b, d, a
+            else:
+                m1, m2, ad = b, a, d
+            m1e = ("-" if neg else "") + D(m1)
+            ade = ("-" if addsub == "sub" else "") + D(ad)
+            return ["%s = B(FMA(%s, %s, %s));" % (d, m1e, D(m2), ade)]
+        if mn in ("vandpd", "vorpd", "vxorpd", "vxorps", "vandps"):
+            c = {"vandpd": "&", "vandps": "&", "vorpd": "|", "vxorpd": "^", "vxorps": "^"}[mn]
+            return ["%s = %s %s %s;" % (dstx(), X(1), c, X(0))]
+        if mn == "vandnpd":
+            return ["%s = (~%s) & %s;" % (dstx(), X(1), X(0))]
+        if mn in ("andpd", "orpd", "xorpd", "pxor", "xorps", "andps"):
+            c = {"andpd": "&", "andps": "&", "orpd": "|", "xorpd": "^", "pxor": "^", "xorps": "^"}[mn]
+            return ["%s = %s %s %s;" % (dstx(), dstx(), c, X(0))]
+        if mn == "vblendvpd":
+            return ["%s = ((%s >> 63) ? %s : %s);" % (dstx(), X(0), X(1), X(2))]
+        m = re.match(r"^vcmp(lt|nlt|le|nle|eq|neq|unord|ord)sd$", mn)
+        if m:
+            a, b = D(X(0)), D(X(1))
+            e = {"lt": "(%s < %s)", "nlt": "!(%s < %s)", "le": "(%s <= %s)", "nle": "!(%s <= %s)",
+                 "eq": "(%s == %s)", "neq": "!(%s == %s)"}[m.group(1)] % (b, a)
+            return ["%s = %s ? ~0ULL : 0ULL;" % (dstx(), e)]
+        if mn in ("vcomisd", "vucomisd", "comisd", "ucomisd"):
+            return ["FCMP(%s, %s);" % (D(X(1)), D(X(0)))]
+        if mn in ("ucomiss", "comiss"):
+            return ["FCMP((double)F(%s), (double)F(%s));" % (self.xread32(ops[1], addr), self.xread32(ops[0], addr))]
+        if mn in ("vmovsd", "movsd", "vmovq", "movq", "movapd", "movaps", "vmovapd", "vmovaps", "movd", "vmovd"):
+            src, dst = ops[0], ops[-1]
+            is32 = mn in ("movd", "vmovd")
+            if dst.startswith("%xmm"):
+                if src.startswith("%") and not src.startswith("%xmm"):
+                    v = self.rreg(src[1:])
+                    return ["x%s = (uint64_t)%s;" % (dst[4:], v)]
+                if is32:
+                    return ["x%s = (uint64_t)%s;" % (dst[4:], self.xread32(src, addr))]
+                return ["x%s = %s;" % (dst[4:], self.xread(src, addr))]
+            if dst.startswith("%"):
+                # xmm -> gpr
+                return [self.wreg(dst[1:], self.xread32(src, addr) if is32 else self.xread(src, addr))]
+            k = self.mem(dst, addr)
+            assert k[0] == "stk", (hex(addr), self.ins[addr])
+            if is32:
+                return ["SETSTK32(%d, %s);" % (k[1], self.xread32(src, addr))]
+            return ["SETSTK64(%d, %s);" % (k[1], self.xread(src, addr))]
+        if mn in ("vcvttsd2si", "cvttsd2si"):
+            w = self.regw(ops[1][1:])
+            return [self.wreg(ops[1][1:], "(%s)CVTT%d(%s)" % (UT[w], w, D(X(0))))]
+        if mn in ("vcvtsi2sd", "cvtsi2sd", "vcvtsi2sdl", "cvtsi2sdl", "vcvtsi2sdq", "cvtsi2sdq"):
+            src = ops[0]
+            w = self.regw(src[1:]) if src.startswith("%") else (64 if mn.endswith("q") else 32)
+            return ["%s = B((double)(%s)%s);" % (dstx(), ST[w], self.iread(src, w, addr))]
+        if mn == "cvtsd2ss":
+            return ["%s = (%s & ~0xffffffffULL) | BF((float)%s);" % (dstx(), dstx(), D(X(0)))]
+        if mn == "cvtss2sd":
+            return ["%s = B((double)F(%s));" % (dstx(), self.xread32(ops[0], addr))]
+
+        # ---- integer
+        if mn in ("mov", "movl", "movq", "movabs", "movb"):
+            w = self.width_of(mn, ops)
+            return [self.iwrite(ops[1], w, self.iread(ops[0], w, addr), addr)]
+        if mn == "movslq":
+            return [self.wreg(ops[1][1:], "(int64_t)(int32_t)%s" % self.iread(ops[0], 32, addr))]
+        if mn in ("movzbl", "movzwl"):
+            w = 8 if mn[4] == "b" else 16
+            return [self.wreg(ops[1][1:], self.iread(ops[0], w, addr))]
+        if mn == "cltq":
+            return ["rax = (uint64_t)(int64_t)(int32_t)rax;"]
+        if mn == "lea":
+            k = self.mem(ops[0], addr)
+            w = self.regw(ops[1][1:])
+            if k[0] == "abs":
+                self.tables.setdefault(k[1], 0)
+                return [self.wreg(ops[1][1:], "0x%xULL" % k[1])]
+            if k[0] == "stk":  # address of a stack slot: only ever an out-parameter of an (out-of-domain) call
+                return [self.wreg(ops[1][1:], "0xdead0000ULL + %d" % k[1])]
+            assert k[0] == "dyn", (hex(addr), self.ins[addr])
+            return [self.wreg(ops[1][1:], k[1])]
+        if mn in ("add", "sub", "and", "or", "xor", "cmp", "test", "addq", "subq", "andl", "cmpl", "testb", "cmpq",
+                  "addl", "subl", "orl", "testl", "andq", "cmpb"):
+            base = mn.rstrip("lqb") if mn not in ("sub", "add", "and", "or", "xor", "cmp", "test") else mn
+            if base == "su":
+                base = "sub"
+            w = self.width_of(mn, ops)
+            if ops[1] == "%rsp":
+                return ["/* rsp adjust */"]
+            a = self.iread(ops[0], w, addr)
+            b = self.iread(ops[1], w, addr)
+            U, S = UT[w], ST[w]
+            if base in ("add", "sub", "cmp"):
+                if base == "add":
+                    o("{ %s a_ = %s, b_ = %s, r_ = (%s)(b_ + a_); cf = (r_ < b_); "
+                      "of = (((%s)(~(a_ ^ b_) & (a_ ^ r_))) < 0); zf = (r_ == 0); sf = ((%s)r_ < 0);"
+                      % (U, a, b, U, S, S))
+                else:
+                    o("{ %s a_ = %s, b_ = %s, r_ = (%s)(b_ - a_); cf = (b_ < a_); "
+                      "of = (((%s)((a_ ^ b_) & (b_ ^ r_))) < 0); zf = (r_ == 0); sf = ((%s)r_ < 0);"
+                      % (U, a, b, U, S, S))
+                if base != "cmp":
+                    o(self.iwrite(ops[1], w, "r_", addr))
+                o("}")
+                return [" ".join(out)]
+            c = {"and": "&", "test": "&", "or": "|", "xor": "^"}[base]
+            o("{ %s r_ = (%s)(%s %s %s); %s" % (U, U, b, c, a, self.flags_logic(w, "r_")))
+            if base != "test":
+                o(self.iwrite(ops[1], w, "r_", addr))
+            o("}")
+            return [" ".join(out)]
+        if mn in ("shl", "shr", "sar", "sal"):
+            w = self.width_of(mn, ops)
+            if len(ops) == 1:
+                ops = ["$1"] + ops
+            if ops[0] == "%cl":
+                n = "(rcx & %d)" % (63 if w == 64 else 31)
+            else:
+                n = "%d" % int(ops[0][1:], 0)
+            b = self.iread(ops[1], w, addr)
+            U, S = UT[w], ST[w]
+            if mn in ("shl", "sal"):
+                e = "(%s)(%s << %s)" % (U, b, n)
+            elif mn == "shr":
+                e = "(%s)(%s >> %s)" % (U, b, n)
+            else:
+                e = "(%s)((%s)%s >> %s)" % (U, S, b, n)
+            return ["{ %s r_ = %s; zf = (r_ == 0); sf = ((%s)r_ < 0); cf = 0; of = 0; %s }"
+                    % (U, e, S, self.iwrite(ops[1], w, "r_", addr))]
+        if mn == "imul":
+            w = self.width_of(mn, ops)
+            if len(ops) == 3:
+                return [self.wreg(ops[2][1:], "(%s)((%s)%s * (%s)%s)" % (UT[w], ST[w], self.iread(ops[1], w, addr),
+                                                                    ST[w], self.iread(ops[0], w, addr)))]
+            return [self.wreg(ops[1][1:], "(%s)((%s)%s * (%s)%s)" % (UT[w], ST[w], self.iread(ops[1], w, addr),
+                                                                ST[w], self.iread(ops[0], w, addr)))]
+        if mn == "not":
+            w = self.width_of(mn, ops)
+            return [self.iwrite(ops[0], w, "~%s" % self.iread(ops[0], w, addr), addr)]
+        if mn == "neg":
+            w = self.width_of(mn, ops)
+            return ["{ %s r_ = (%s)(0 - %s); zf = (r_ == 0); sf = ((%s)r_ < 0); cf = (r_ != 0); of = 0; %s }"
+                    % (UT[w], UT[w], self.iread(ops[0], w, addr), ST[w], self.iwrite(ops[0], w, "r_", addr))]
+        if mn in ("bt", "btc", "btr", "bts"):
+            w = self.width_of(mn, ops)
+            if ops[0].startswith("%"):
+                n = "(%s & %d)" % (self.rreg(ops[0][1:]), w - 1)
+            else:
+                n = "%d" % int(ops[0][1:], 0)
+            b = self.iread(ops[1], w, addr)
+            s = "cf = (int)((%s >> %s) & 1);" % (b, n)
+            if mn == "btc":
+                s += " " + self.iwrite(ops[1], w, "%s ^ ((%s)1 << %s)" % (b, UT[w], n), addr)
+            if mn == "btr":
+                s += " " + self.iwrite(ops[1], w, "%s & ~((%s)1 << %s)" % (b, UT[w], n), addr)
+            if mn == "bts":
+                s += " " + self.iwrite(ops[1], w, "%s | ((%s)1 << %s)" % (b, UT[w], n), addr)
+            return [s]
+        raise NotImplementedError("%x: %s" % (addr, self.ins[addr]))
+
+    @staticmethod
+    def cond(cc):
+        return {
+            "e": "zf", "z": "zf", "ne": "!zf", "nz": "!zf",
+            "a": "(!cf && !zf)", "ae": "!cf", "nb": "!cf", "b": "cf", "be": "(cf || zf)", "c": "cf", "nc": "!cf",
+            "g": "(!zf && sf == of)", "ge": "(sf == of)", "l": "(sf != of)", "le": "(zf || sf != of)",
+            "s": "sf", "ns": "!sf", "p": "pf", "np": "!pf",
+        }[cc]
+
+    # ---------------- whole function -----------------
+    def lift(self, name, entry, end, nargs):
+        region = (entry, end)
+        seen, work, targets = set(), [entry], set()
+        while work:
+            a = work.pop()
+            while a not in seen and entry <= a < end:
+                seen.add(a)
+                mn, ops = self.parse(a)
+                if mn == "ret":
+                    break
+                if mn == "call":
+                    break  # every call here is a noreturn/error/out-of-domain exit
+                if mn.startswith("j"):
+                    tgt = int(ops[0], 16)
+                    if entry <= tgt < end:
+                        work.append(tgt)
+                        targets.add(tgt)
+                    if mn == "jmp":
+                        break
+                a = self.nxt[a]
+        body = []
+        addrs = sorted(seen)
+        for i, a in enumerate(addrs):
+            stmts = self.emit(a, region)
+            lab = "L%x: " % a if a in targets else ""
+            body.append("  %s%s" % (lab, " ".join(stmts)))
+            mn, _ = self.parse(a)
+            if mn not in ("ret", "jmp", "call") and self.nxt[a] not in seen:
+                body.append("  *ood = 1; return D(0x7ff8000000000000ULL); /* falls out of region */")
+        text = "\n".join(body)
+        args = "double a0" + (", double a1" if nargs == 2 else "")
+        pro = ["RPP_HD static inline double rpp_glibc_%s_raw(%s, int *ood) {" % (name, args),
+               "  uint64_t rax=0,rbx=0,rcx=0,rdx=0,rsi=0,rdi=0,rbp=0,r8=0,r9=0,r10=0,r11=0,r12=0,r13=0,r14=0,r15=0;",
+               "  uint64_t x0=B(a0),x1=%s,x2=0,x3=0,x4=0,x5=0,x6=0,x7=0,x8=0,x9=0,x10=0,x11=0,x12=0,x13=0,x14=0,x15=0;"
+               % ("B(a1)" if nargs == 2 else "0"),
+               "  int zf=0,cf=0,sf=0,of=0,pf=0; uint32_t stk[32];",
+               "  for (int i_ = 0; i_ < 32; ++i_) stk[i_] = 0;",
+               "  (void)rax;(void)rbx;(void)rcx;(void)rdx;(void)rsi;(void)rdi;(void)rbp;(void)r8;(void)r9;(void)r10;"
+               "(void)r11;(void)r12;(void)r13;(void)r14;(void)r15;",
+               "  (void)x1;(void)x2;(void)x3;(void)x4;(void)x5;(void)x6;(void)x7;(void)x8;(void)x9;(void)x10;(void)x11;"
+               "(void)x12;(void)x13;(void)x14;(void)x15;(void)zf;(void)cf;(void)sf;(void)of;(void)pf;"]
+        return "\n".join(pro) + "\n" + text + "\n}\n"
+
+
+HEADER = r"""// GENERATED by tools/lift_libm.py -- do not edit.
+// Operation-by-operation restatement of glibc %(ver)s x86-64 FMA-variant
+// pow / atan2 / sin / cos (the entry points CPython's math.* and float ** reach
+// on this image), so that device code takes the same roundings as the reference
+// planners' CPython arithmetic (rrt_04:1100-1101,1198,1236-1237 etc).
+// libm sha256: %(sha)s
+#pragma once
+#include <stdint.h>
+#ifndef RPP_HD
+#if defined(__HIPCC__)
+#define RPP_HD __device__
+#else
+#define RPP_HD
+#endif
+#endif
+#ifndef RPP_GLIBC_HELPERS
+#define RPP_GLIBC_HELPERS
+RPP_HD static inline double rpp_b2d(uint64_t b) { double d; __builtin_memcpy(&d, &b, 8); return d; }
+RPP_HD static inline uint64_t rpp_d2b(double d) { uint64_t b; __builtin_memcpy(&b, &d, 8); return b; }
+RPP_HD static inline float rpp_b2f(uint32_t b) { float d; __builtin_memcpy(&d, &b, 4); return d; }
+RPP_HD static inline uint32_t rpp_f2b(float d) { uint32_t b; __builtin_memcpy(&b, &d, 4); return b; }
+RPP_HD static inline int64_t rpp_cvtt64(double d) {
+  if (!(d > -9223372036854775808.0 && d < 9223372036854775808.0)) return (int64_t)0x8000000000000000ULL;
+  return (int64_t)d;
+}
+RPP_HD static inline int32_t rpp_cvtt32(double d) {
+  if (!(d > -2147483649.0 && d < 2147483648.0)) return (int32_t)0x80000000U;
+  return (int32_t)d;
+}
+#endif
+"""
+
+MACROS = r"""
+#define D(b) rpp_b2d(b)
+#define B(d) rpp_d2b(d)
+#define F(b) rpp_b2f(b)
+#define BF(f) ((uint64_t)rpp_f2b(f))
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define CVTT64(d) rpp_cvtt64(d)
+#define CVTT32(d) rpp_cvtt32(d)
+#define FCMP(a, b) do { double a_ = (a), b_ = (b); if (a_ != a_ || b_ != b_) { zf = 1; pf = 1; cf = 1; } \
+  else if (a_ > b_) { zf = 0; pf = 0; cf = 0; } else if (a_ < b_) { zf = 0; pf = 0; cf = 1; } \
+  else { zf = 1; pf = 0; cf = 0; } sf = 0; of = 0; } while (0)
+#define STK32(o) (stk[(o) >> 2])
+#define STK64(o) ((uint64_t)stk[(o) >> 2] | ((uint64_t)stk[((o) >> 2) + 1] << 32))
+#define SETSTK32(o, v) do { stk[(o) >> 2] = (uint32_t)(v); } while (0)
+#define SETSTK64(o, v) do { uint64_t v_ = (v); stk[(o) >> 2] = (uint32_t)v_; stk[((o) >> 2) + 1] = (uint32_t)(v_ >> 32); } while (0)
+#define SETSTK8(o, v) do { uint32_t s_ = ((o) & 3) * 8; stk[(o) >> 2] = (stk[(o) >> 2] & ~(0xffu << s_)) | ((uint32_t)(uint8_t)(v) << s_); } while (0)
+#define STK8(o) ((uint8_t)(stk[(o) >> 2] >> (((o) & 3) * 8)))
+#define ROM64(a) rpp_glibc_rom64(a)
+#define ROM32(a) ((uint32_t)rpp_glibc_rom64(a))
+"""
+
+UNMACROS = """
+#undef D
+#undef B
+#undef F
+#undef BF
+#undef FMA
+#undef CVTT64
+#undef CVTT32
+#undef FCMP
+#undef STK32
+#undef STK64
+#undef SETSTK32
+#undef SETSTK64
+#undef SETSTK8
+#undef STK8
+#undef ROM64
+#undef ROM32
+"""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--libm", default="/lib/x86_64-linux-gnu/libm.so.6")
+    ap.add_argument("--out", default="robotics-path-planning_amd/csrc/glibc235_fma_math.h")
+    ap.add_argument("--tables", default=None,
+                    help="comma list base:size (hex) of lookup tables reached through lea; printed when omitted")
+    a = ap.parse_args()
+    L = Lifter(a.libm)
+    sha = hashlib.sha256(L.blob).hexdigest()
+    ver = subprocess.run(["ldd", "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+    bodies = []
+    for name, entry, end, nargs in FUNCS:
+        bodies.append(L.lift(name, entry, end, nargs))
+    if a.tables is None:
+        print("lea targets:", " ".join(hex(t) for t in sorted(L.tables)))
+        return 1
+    tabs = []
+    for t in a.tables.split(","):
+        b, s = t.split(":")
+        tabs.append((int(b, 16), int(s, 16)))
+    rom = ["// lookup tables (copied as data from .rodata of the libm named above)"]
+    sel = []
+    for (b, s) in tabs:
+        n = s // 8
+        vals = [L.rd64(b + 8 * i) for i in range(n)]
+        rom.append("RPP_ROM static const uint64_t rpp_glibc_rom_%x[%d] = {" % (b, n))
+        for i in range(0, n, 4):
+            rom.append("  " + ", ".join("0x%016xULL" % v for v in vals[i:i + 4]) + ",")
+        rom.append("};")
+        sel.append("  if (a - 0x%xULL < 0x%xULL) return rpp_glibc_rom_%x[(a - 0x%xULL) >> 3];" % (b, s, b, b))
+    rom.append("RPP_HD static inline uint64_t rpp_glibc_rom64(uint64_t a) {")
+    rom += sel
+    rom.append("  return 0x7ff8000000000000ULL;")
+    rom.append("}")
+    with open(a.out, "w") as f:
+        f.write(HEADER % {"ver": ver, "sha": sha})
+        f.write("#ifndef RPP_ROM\n#if defined(__HIPCC__)\n#define RPP_ROM __device__\n#else\n#define RPP_ROM\n#endif\n#endif\n")
+        f.write("\n".join(rom) + "\n")
+        f.write(MACROS)
+        for b in bodies:
+            f.write("\n" + b)
+        f.write(UNMACROS)
+        f.write("""
+// out-of-domain (huge |x| needing Payne-Hanek, pow over/underflow) yields NaN.
+RPP_HD static inline double rpp_glibc_sin(double x) { int o = 0; return rpp_glibc_sin_raw(x, &o); }
+RPP_HD static inline double rpp_glibc_cos(double x) { int o = 0; return rpp_glibc_cos_raw(x, &o); }
+RPP_HD static inline double rpp_glibc_atan2(double y, double x) { int o = 0; return rpp_glibc_atan2_raw(y, x, &o); }
+RPP_HD static inline double rpp_glibc_pow(double x, double y) { int o = 0; return rpp_glibc_pow_raw(x, y, &o); }
+""")
+    print("wrote", a.out)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
