@@ -1,0 +1,136 @@
+/*
+ * rrtx.h -- C ABI of the MI355X-native batched RRT / RRT* planner.
+ *
+ * The reference (gouldberg/robotics-path-planning) has no FFI layer: its
+ * boundary is the Python class surface `RRT(...).planning(animation)` and the
+ * attributes callers read afterwards.  This ABI is what a ctypes
+ * binding on the reference side calls in place of the body of
+ *   10_path_planning_01_rrt_01_simple.py   RRT.planning            :71-101
+ *   10_path_planning_01_rrt_04_rrt_star.py RRT.planning            :1036-1084
+ * Each entry point names the reference interface it replaces.  Plain pointers
+ * and sizes only; the caller owns every host buffer, the library owns device
+ * memory behind the opaque handle.  Every function returns 0 or a negative
+ * RRTX_E_* code and never throws.  A handle is bound to one device and is not
+ * thread safe (one host thread per handle; multi-GPU = one handle per device).
+ * There is NO CPU fallback: without a usable gfx950 device rrtx_create fails
+ * with RRTX_E_NO_DEVICE.
+ */
+#ifndef RRTX_H
+#define RRTX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTX_ABI_VERSION 1
+
+enum {
+  RRTX_OK = 0,
+  RRTX_E_INVALID = -1,     /* bad argument / unsupported parameter combination */
+  RRTX_E_NO_DEVICE = -2,   /* no HIP device, or not gfx950 */
+  RRTX_E_HIP = -3,         /* HIP runtime error, see rrtx_last_error */
+  RRTX_E_CAPACITY = -4,    /* caller buffer too small */
+  RRTX_E_STATE = -5,       /* call order (e.g. get_tree before plan) */
+  RRTX_E_OVERFLOW = -6     /* an on-device work list exceeded its fixed capacity; result invalid */
+};
+
+enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
+       RRTX_ALGO_RRT_STAR = 1   /* rrt_04 RRT.planning :1036-1084 */ };
+enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
+       RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
+
+/* per-instance status bits (rrtx_get_results) */
+enum { RRTX_ST_DONE = 1, RRTX_ST_PATH = 2, RRTX_ST_OVERFLOW = 4, RRTX_ST_PATH_TRUNC = 8 };
+
+/* Constructor arguments of the reference classes (rrt_04:951-1000, rrt_01:32-69). */
+typedef struct rrtx_params {
+  int32_t abi_version;           /* RRTX_ABI_VERSION */
+  int32_t algo;                  /* RRTX_ALGO_* */
+  int32_t sampler;               /* sobol_sampler (rrt_04:962) */
+  int32_t goal_sample_rate;      /* rrt_04:958 */
+  int32_t max_iter;              /* rrt_04:959 */
+  int32_t has_play_area;         /* play_area is not None (rrt_04:981) */
+  int32_t search_until_max_iter; /* rrt_04:964 */
+  int32_t n_instances;           /* independent planning instances resident on the device */
+  int32_t device;                /* HIP device ordinal */
+  int32_t reserved_i[7];
+  double start[3];               /* start [x,y,(yaw)] rrt_04:977 */
+  double goal[3];                /* goal  [x,y,(yaw)] rrt_04:978 */
+  double rand_min, rand_max;     /* rand_area rrt_04:979-980 */
+  double expand_dis;             /* rrt_04:985 */
+  double path_resolution;        /* rrt_04:986 */
+  double play_area[4];           /* xmin xmax ymin ymax (rrt_04:944-949) */
+  double robot_radius;           /* rrt_04:991 */
+  double connect_circle_dist;    /* rrt_04:998 */
+  double reserved_d[8];
+} rrtx_params;
+
+/* Aggregate counters over all instances of the last rrtx_plan(). */
+typedef struct rrtx_stats {
+  int64_t iterations;        /* loop iterations executed (rrt_04:1044) */
+  int64_t edges_unique;      /* collision-checked edge expansions actually evaluated on the device */
+  int64_t edges_ref;         /* check_collision calls the reference would have made (repeated near indices counted) */
+  int64_t near_hits;         /* sum of len(near_inds) (rrt_04:1337) */
+  int64_t near_unique;       /* distinct indices among them */
+  int64_t rewires;           /* rrt_04:1368 successes */
+  int64_t propagated;        /* nodes rewritten by propagate_cost_to_leaves (rrt_04:1379-1384) */
+  int64_t scan_nodes;        /* nodes visited by nearest/near/goal scans */
+  int64_t algorithmic_bytes; /* sum over iterations of 16*n per scan + 48*k + 24*M + 28 */
+  int64_t exact_rescans;     /* nearest scans re-done with exact ** 2 (tie within filter margin) */
+  int64_t total_nodes;
+  int64_t launches;          /* kernel launches */
+  double kernel_ms;          /* HIP-event time of all planner-kernel launches on the handle's stream */
+  double plan_ms;            /* host wall time of rrtx_plan */
+  int64_t reserved[8];
+} rrtx_stats;
+
+typedef struct rrtx_handle rrtx_handle;
+
+/* replaces RRT.__init__ (rrt_04:951-1000); allocates device state for n_instances trees of max_iter+1 nodes. */
+int rrtx_create(const rrtx_params* p, rrtx_handle** out);
+/* obstacle_list ctor argument (rrt_04:989): m rows of (ox, oy, size), AoS in; converted to SoA + thresholds
+ * (size+robot_radius)**2 (rrt_04:1227) on the host.  Shared by all instances of the handle. */
+int rrtx_set_obstacles(rrtx_handle* h, const double* oxyr, int32_t m);
+/* hand over / take back CPython's `random.getstate()[1]` (624 words + position) for one instance, so that
+ * the device consumes the stream exactly as random.randint / random.uniform would (rrt_04:1133-1136). */
+int rrtx_set_rng_state(rrtx_handle* h, int32_t instance, const uint32_t* mt624, int32_t pos);
+int rrtx_get_rng_state(rrtx_handle* h, int32_t instance, uint32_t* mt624, int32_t* pos);
+/* convenience: state after `random.seed(seed)` for instances first..first+count-1 */
+int rrtx_seed_instances(rrtx_handle* h, int32_t first, int32_t count, const uint64_t* seeds);
+/* per-instance start / goal for batches (default: the ctor's) */
+int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, const double* goal3);
+/* replaces the body of RRT.planning(animation=False) for every instance; blocking. */
+int rrtx_plan(rrtx_handle* h);
+/* rrt.node_list as SoA: x, y, cost (f64), parent (i32, -1 = None); any pointer may be NULL. */
+int rrtx_get_tree(rrtx_handle* h, int32_t instance, double* x, double* y, double* cost, int32_t* parent,
+                  int32_t cap, int32_t* n_out);
+/* return value of planning(): n_out points [x,y] goal -> start (rrt_04:1117-1125); n_out = 0 <=> None. */
+int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_points, int32_t* n_out);
+/* per-instance result table {path_cost = get_path_length(path) (rrt_04:1391-1399), n_nodes, status};
+ * this 16-byte record is what multi-GPU runs gather over RCCL. */
+int rrtx_get_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status);
+/* device pointer + byte size of the packed result table (n_instances x {f64 cost, i32 n, i32 status}) */
+int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes);
+/* Sobol index (RRT.sobol_inter_, rrt_04:995,1148) after planning */
+int rrtx_get_sobol_index(rrtx_handle* h, int32_t instance, int64_t* index);
+int rrtx_get_stats(rrtx_handle* h, rrtx_stats* st);
+/* optional per-iteration trace of one instance (debug/parity harness): call before rrtx_plan.
+ * rows: rnd_x, rnd_y (f64), nearest, n_near_unique (i32; -1 when the iteration stopped before the near query) */
+int rrtx_enable_trace(rrtx_handle* h, int32_t instance);
+int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* nearest, int32_t* n_near,
+                   int32_t cap, int32_t* n_out);
+const char* rrtx_last_error(rrtx_handle* h);
+void rrtx_destroy(rrtx_handle* h);
+
+/* library-level */
+int rrtx_abi_version(void);
+int rrtx_device_count(void);
+/* Evaluate the device scalar core on arrays (parity harness for the glibc/CPython arithmetic replicas):
+ * op 0: math.hypot(a,b)  1: a**2  2: math.sin(a)  3: math.cos(a)  4: math.atan2(a,b)
+ * op 5: steer end x of (0,0)->(a,b) with extend=inf, res=0.25   6: sqrt(a)  7: a/b */
+int rrtx_selftest_math(int32_t device, int32_t op, const double* a, const double* b, double* out, int64_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,239 @@
+"""ctypes binding of librrtx.so (the C ABI in include/rrtx.h).
+
+There is no Python or CPU fallback: if the shared library is missing, or no
+gfx950 device is usable, planning raises.  Build with
+`make -C robotics-path-planning_amd/csrc` (or `__graft_entry__.build()`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrtx.so")
+
+RRTX_ABI_VERSION = 1
+ALGO_RRT, ALGO_RRT_STAR = 0, 1
+SAMPLER_MT, SAMPLER_SOBOL = 0, 1
+ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC = 1, 2, 4, 8
+ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
+          -5: "RRTX_E_STATE", -6: "RRTX_E_OVERFLOW"}
+
+EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
+           "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_plan", "rrtx_get_tree",
+           "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_stats",
+           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math"]
+
+
+class Params(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("algo", C.c_int32), ("sampler", C.c_int32),
+                ("goal_sample_rate", C.c_int32), ("max_iter", C.c_int32), ("has_play_area", C.c_int32),
+                ("search_until_max_iter", C.c_int32), ("n_instances", C.c_int32), ("device", C.c_int32),
+                ("reserved_i", C.c_int32 * 7),
+                ("start", C.c_double * 3), ("goal", C.c_double * 3),
+                ("rand_min", C.c_double), ("rand_max", C.c_double),
+                ("expand_dis", C.c_double), ("path_resolution", C.c_double),
+                ("play_area", C.c_double * 4), ("robot_radius", C.c_double),
+                ("connect_circle_dist", C.c_double), ("reserved_d", C.c_double * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_int64), ("edges_unique", C.c_int64), ("edges_ref", C.c_int64),
+                ("near_hits", C.c_int64), ("near_unique", C.c_int64), ("rewires", C.c_int64),
+                ("propagated", C.c_int64), ("scan_nodes", C.c_int64), ("algorithmic_bytes", C.c_int64),
+                ("exact_rescans", C.c_int64), ("total_nodes", C.c_int64), ("launches", C.c_int64),
+                ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("reserved", C.c_int64 * 8)]
+
+
+class RrtxError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load librrtx.so; raises RrtxError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RrtxError("librrtx.so not built (%s); run `make -C robotics-path-planning_amd/csrc` -- there is no "
+                        "CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    L.rrtx_abi_version.restype = C.c_int
+    L.rrtx_device_count.restype = C.c_int
+    L.rrtx_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.rrtx_set_obstacles.argtypes = [vp, vp, i32]
+    L.rrtx_set_rng_state.argtypes = [vp, i32, vp, i32]
+    L.rrtx_get_rng_state.argtypes = [vp, i32, vp, C.POINTER(i32)]
+    L.rrtx_seed_instances.argtypes = [vp, i32, i32, vp]
+    L.rrtx_set_instance.argtypes = [vp, i32, vp, vp]
+    L.rrtx_plan.argtypes = [vp]
+    L.rrtx_get_tree.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.POINTER(i32)]
+    L.rrtx_get_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.rrtx_get_results.argtypes = [vp, vp, vp, vp]
+    L.rrtx_results_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
+    L.rrtx_get_sobol_index.argtypes = [vp, i32, i64p]
+    L.rrtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.rrtx_enable_trace.argtypes = [vp, i32]
+    L.rrtx_get_trace.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
+    L.rrtx_last_error.argtypes = [vp]
+    L.rrtx_last_error.restype = C.c_char_p
+    L.rrtx_destroy.argtypes = [vp]
+    L.rrtx_destroy.restype = None
+    L.rrtx_selftest_math.argtypes = [i32, i32, vp, vp, vp, C.c_int64]
+    for f in EXPORTS:
+        if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
+            getattr(L, f).restype = C.c_int
+    if L.rrtx_abi_version() != RRTX_ABI_VERSION:
+        raise RrtxError("librrtx.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+class Handle:
+    """Thin RAII wrapper over rrtx_handle*."""
+
+    def __init__(self, algo, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
+                 play_area=None, robot_radius=0.0, sampler=SAMPLER_MT, connect_circle_dist=50.0,
+                 search_until_max_iter=False, n_instances=1, device=0):
+        self.L = load()
+        p = Params()
+        p.abi_version = RRTX_ABI_VERSION
+        p.algo, p.sampler = int(algo), int(sampler)
+        p.goal_sample_rate, p.max_iter = int(goal_sample_rate), int(max_iter)
+        p.has_play_area = 0 if play_area is None else 1
+        p.search_until_max_iter = int(bool(search_until_max_iter))
+        p.n_instances, p.device = int(n_instances), int(device)
+        for i in range(min(3, len(start))):
+            p.start[i] = float(start[i])
+        for i in range(min(3, len(goal))):
+            p.goal[i] = float(goal[i])
+        p.rand_min, p.rand_max = float(rand_area[0]), float(rand_area[1])
+        p.expand_dis, p.path_resolution = float(expand_dis), float(path_resolution)
+        if play_area is not None:
+            for i in range(4):
+                p.play_area[i] = float(play_area[i])
+        p.robot_radius = float(robot_radius)
+        p.connect_circle_dist = float(connect_circle_dist)
+        self.params = p
+        self.n_instances = int(n_instances)
+        self.max_iter = int(max_iter)
+        self._h = C.c_void_p()
+        rc = self.L.rrtx_create(C.byref(p), C.byref(self._h))
+        if rc != 0:
+            msg = self.L.rrtx_last_error(self._h).decode() if self._h else ""
+            if self._h:
+                self.L.rrtx_destroy(self._h)
+                self._h = C.c_void_p()
+            raise RrtxError("rrtx_create: %s %s" % (ERRORS.get(rc, rc), msg))
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RrtxError("%s: %s %s" % (what, ERRORS.get(rc, rc), self.L.rrtx_last_error(self._h).decode()))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.rrtx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_obstacles(self, obstacle_list):
+        a = np.ascontiguousarray(np.array([[float(v) for v in o] for o in obstacle_list], dtype=np.float64)
+                                 .reshape(-1, 3))
+        self._chk(self.L.rrtx_set_obstacles(self._h, a.ctypes.data, len(a)), "rrtx_set_obstacles")
+
+    def set_rng_state(self, instance, pystate):
+        """pystate = random.getstate()"""
+        words = np.array(pystate[1][:624], dtype=np.uint32)
+        self._chk(self.L.rrtx_set_rng_state(self._h, instance, words.ctypes.data, int(pystate[1][624])),
+                  "rrtx_set_rng_state")
+
+    def get_rng_state(self, instance, gauss_next=None):
+        words = np.zeros(624, dtype=np.uint32)
+        pos = C.c_int32()
+        self._chk(self.L.rrtx_get_rng_state(self._h, instance, words.ctypes.data, C.byref(pos)), "rrtx_get_rng_state")
+        return (3, tuple(int(w) for w in words) + (int(pos.value),), gauss_next)
+
+    def seed_instances(self, seeds, first=0):
+        s = np.ascontiguousarray(np.array([abs(int(v)) for v in seeds], dtype=np.uint64))
+        self._chk(self.L.rrtx_seed_instances(self._h, first, len(s), s.ctypes.data), "rrtx_seed_instances")
+
+    def set_instance(self, instance, start=None, goal=None):
+        s = (C.c_double * 3)(*([float(v) for v in start] + [0.0] * (3 - len(start)))) if start is not None else None
+        g = (C.c_double * 3)(*([float(v) for v in goal] + [0.0] * (3 - len(goal)))) if goal is not None else None
+        self._chk(self.L.rrtx_set_instance(self._h, instance, C.cast(s, C.c_void_p) if s else None,
+                                           C.cast(g, C.c_void_p) if g else None), "rrtx_set_instance")
+
+    def enable_trace(self, instance):
+        self._chk(self.L.rrtx_enable_trace(self._h, instance), "rrtx_enable_trace")
+
+    def plan(self):
+        self._chk(self.L.rrtx_plan(self._h), "rrtx_plan")
+
+    def get_tree(self, instance=0):
+        n = C.c_int32()
+        self._chk(self.L.rrtx_get_tree(self._h, instance, None, None, None, None, 0, C.byref(n)), "rrtx_get_tree")
+        k = n.value
+        x = np.zeros(k); y = np.zeros(k); cost = np.zeros(k); parent = np.zeros(k, dtype=np.int32)
+        self._chk(self.L.rrtx_get_tree(self._h, instance, x.ctypes.data, y.ctypes.data, cost.ctypes.data,
+                                       parent.ctypes.data, k, C.byref(n)), "rrtx_get_tree")
+        return x, y, cost, parent
+
+    def get_path(self, instance=0):
+        n = C.c_int32()
+        self._chk(self.L.rrtx_get_path(self._h, instance, None, 0, C.byref(n)), "rrtx_get_path")
+        if n.value == 0:
+            return None
+        xy = np.zeros((n.value, 2))
+        self._chk(self.L.rrtx_get_path(self._h, instance, xy.ctypes.data, n.value, C.byref(n)), "rrtx_get_path")
+        return xy
+
+    def get_results(self):
+        B = self.n_instances
+        pc = np.zeros(B); nn = np.zeros(B, dtype=np.int32); st = np.zeros(B, dtype=np.int32)
+        self._chk(self.L.rrtx_get_results(self._h, pc.ctypes.data, nn.ctypes.data, st.ctypes.data),
+                  "rrtx_get_results")
+        return pc, nn, st
+
+    def results_device_ptr(self):
+        p = C.c_void_p(); b = C.c_int64()
+        self._chk(self.L.rrtx_results_device_ptr(self._h, C.byref(p), C.byref(b)), "rrtx_results_device_ptr")
+        return p.value, b.value
+
+    def get_sobol_index(self, instance=0):
+        v = C.c_int64()
+        self._chk(self.L.rrtx_get_sobol_index(self._h, instance, C.byref(v)), "rrtx_get_sobol_index")
+        return v.value
+
+    def get_stats(self):
+        s = Stats()
+        self._chk(self.L.rrtx_get_stats(self._h, C.byref(s)), "rrtx_get_stats")
+        return {k: getattr(s, k) for k, _ in Stats._fields_ if k != "reserved"}
+
+    def get_trace(self):
+        n = C.c_int32()
+        cap = self.max_iter + 1
+        rx = np.zeros(cap); ry = np.zeros(cap); ne = np.zeros(cap, dtype=np.int32); nn = np.zeros(cap, dtype=np.int32)
+        self._chk(self.L.rrtx_get_trace(self._h, rx.ctypes.data, ry.ctypes.data, ne.ctypes.data, nn.ctypes.data, cap,
+                                        C.byref(n)), "rrtx_get_trace")
+        k = n.value
+        return rx[:k], ry[:k], ne[:k], nn[:k]
+
+
+def selftest_math(op, a, b, device=0):
+    L = load()
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.zeros_like(a)
+    rc = L.rrtx_selftest_math(device, op, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+    if rc != 0:
+        raise RrtxError("rrtx_selftest_math: %s" % ERRORS.get(rc, rc))
+    return out

@@ -1,0 +1,832 @@
+// rrt_kernels.hip.h -- gfx950 kernels of the batched RRT / RRT* planner.
+//
+// One 256-thread workgroup (4 wave64) owns one planning instance and runs its
+// iterations back to back on the device; many instances are resident per GPU
+// (4 workgroups per CU), which is what turns the two O(n) node-array scans of
+// every iteration into an HBM-streaming workload.
+//
+// HBM layout per instance (SoA, stride `stride` nodes, padded with +inf so the
+// scans need no bounds checks):  x[], y[] f64 (the only arrays the scans read:
+// 16 B/node), cost[] f64, parent[] i32, first_child/next_sib/prev_sib i32 (child
+// lists = the identity scans of rrt_04:1369-1371 and :1381-1384 with integer
+// parents), hits[] / stack[] i32 scratch.
+//
+// Per-iteration phases (reference: 10_path_planning_01_rrt_04_rrt_star.py)
+//   sample        lane 0, MT19937 / Sobol                     :1132-1153
+//   nearest       all lanes, wave-contiguous streaming argmin  :1197-1202
+//   steer+collide lane 0 steer, lanes over obstacles (LDS)     :1086-1115, :1216-1230
+//   near          all lanes, streaming threshold scan with ballot-ordered
+//                 compaction, exact **2 re-check, `.index` de-dup   :1314-1338
+//   choose_parent lanes over candidates x obstacles            :1242-1282
+//   rewire        parallel steer/collision, sequential cost resolution and
+//                 cost propagation through child lists         :1340-1384
+//   goal search   streaming scan + candidates                  :1284-1312
+//
+// Exactness: the scans filter with correctly rounded dx*dx+dy*dy, which is within
+// 2^-51 (relative) of the reference's dx**2+dy**2 (glibc pow, < 1 ULP); every
+// decision inside the filter margin 2^-47 is re-taken with the exact replica
+// (rpp::py_d2 / rpp::py_hypot), so integer results equal the reference's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rpp_core.h"
+
+namespace rppk {
+
+constexpr int TPB = 256;
+constexpr int NW = TPB / 64;
+constexpr int UNROLL = 4;
+constexpr int WAVE_STRIDE = 128 * UNROLL;  // nodes one wave consumes per loop trip
+constexpr int MAX_OBS = 256;
+constexpr int NU_MAX = 512;   // distinct near candidates kept in LDS
+constexpr int EB = 64;        // edges steered per pass
+constexpr double FILTER_EPS = 7.105427357601002e-15;  // 2^-47
+
+struct Result {  // 16 B record gathered across GPUs
+  double path_cost;
+  int32_t n_nodes;
+  int32_t status;
+};
+
+struct Inst {  // persistent per-instance state (global memory)
+  rpp::MT rng;
+  rpp::Sobol sobol;
+  double start[2], goal[2];
+  int32_t n, it, status, goal_node, path_n, pad_;
+  int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
+      exact_rescans;
+};
+
+struct Ctx {
+  Inst* inst;
+  double *x, *y, *cost;
+  int32_t *parent, *first_child, *next_sib, *prev_sib, *hits, *stack;
+  int64_t stride;
+  const double *ox, *oy, *othr;
+  int32_t m;
+  const double* r2tab;
+  double* path_xy;
+  int32_t path_cap;
+  Result* results;
+  int32_t algo, sampler, goal_sample_rate, max_iter, has_play, until_max;
+  double rand_min, rand_max, expand_dis, res;
+  double play_area[4];
+  int32_t trace_inst;
+  double *tr_rx, *tr_ry;
+  int32_t *tr_near, *tr_nn;
+};
+
+struct Sh {
+  rpp::MT rng;
+  double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
+  rpp::Edge edge[EB];
+  int32_t ecoll[EB];
+  double uval[NU_MAX];
+  int32_t uidx[NU_MAX];
+  double uex[NU_MAX], uey[NU_MAX], uaux[NU_MAX];
+  int32_t usafe[NU_MAX];
+  double cval[TPB];
+  int32_t cflag[TPB];
+  double red_best[NW], red_second[NW];
+  int32_t red_idx[NW];
+  int32_t wave_cnt[NW];
+  int32_t wave_start[NW];
+  double rx, ry, nx, ny, ncost, wx, wy, wcost;
+  int32_t ni, flag, nu, nvalid, sel, overflow;
+};
+
+__device__ __forceinline__ int roundup_i(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------
+// block-wide (value, index) argmin with lowest-index tie break; `second` is the
+// smallest value held by any element other than the winner (for the filter).
+__device__ __forceinline__ void block_argmin(double best, int bidx, double second, Sh& sh, double& gbest, int& gidx,
+                                             double& gsecond) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double b = best;
+  int bi = bidx;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    double ob = __shfl_xor(b, o);
+    int oi = __shfl_xor(bi, o);
+    bool take = (ob < b) || (ob == b && oi < bi);
+    b = take ? ob : b;
+    bi = take ? oi : bi;
+  }
+  double s = (bidx == bi) ? second : best;  // best <= second always
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    double os = __shfl_xor(s, o);
+    s = os < s ? os : s;
+  }
+  if (lane == 0) {
+    sh.red_best[w] = b;
+    sh.red_idx[w] = bi;
+    sh.red_second[w] = s;
+  }
+  __syncthreads();
+  double gb = sh.red_best[0];
+  int gi = sh.red_idx[0];
+#pragma unroll
+  for (int k = 1; k < NW; k++) {
+    double ob = sh.red_best[k];
+    int oi = sh.red_idx[k];
+    bool take = (ob < gb) || (ob == gb && oi < gi);
+    gb = take ? ob : gb;
+    gi = take ? oi : gi;
+  }
+  double gs = rpp::dinf();
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    double c = (sh.red_idx[k] == gi) ? sh.red_second[k] : sh.red_best[k];
+    gs = c < gs ? c : gs;
+  }
+  gbest = gb;
+  gidx = gi;
+  gsecond = gs;
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Streaming argmin of dx*dx+dy*dy over x[0..n), y[0..n): each wave streams one
+// contiguous quarter with 16-byte loads (lane -> 2 adjacent nodes), UNROLL
+// independent load pairs in flight per lane.  Arrays are +inf padded.
+__device__ __forceinline__ void scan_nearest(const double* __restrict__ x, const double* __restrict__ y, int n,
+                                             double qx, double qy, Sh& sh, int& ni, double& gbest, double& gsecond) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
+  const int ws = w * per;
+  const int we = ws + per;
+  double best = rpp::dinf(), second = rpp::dinf();
+  int bidx = 0x7fffffff;
+  for (int base = ws; base < we && base < n; base += WAVE_STRIDE) {
+    double2 xv[UNROLL], yv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 128 + lane * 2;
+      xv[u] = *reinterpret_cast<const double2*>(x + i0);
+      yv[u] = *reinterpret_cast<const double2*>(y + i0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 128 + lane * 2;
+      {
+        double dx = xv[u].x - qx, dy = yv[u].x - qy;
+        double d = dx * dx + dy * dy;
+        bool lt = d < best;
+        second = lt ? best : (d < second ? d : second);
+        bidx = lt ? i0 : bidx;
+        best = lt ? d : best;
+      }
+      {
+        double dx = xv[u].y - qx, dy = yv[u].y - qy;
+        double d = dx * dx + dy * dy;
+        bool lt = d < best;
+        second = lt ? best : (d < second ? d : second);
+        bidx = lt ? i0 + 1 : bidx;
+        best = lt ? d : best;
+      }
+    }
+  }
+  block_argmin(best, bidx, second, sh, gbest, ni, gsecond);
+}
+
+// ---------------------------------------------------------------------------
+// Streaming threshold scan: indices with dx*dx+dy*dy <= thr are appended, in
+// ascending order, to hits[] (wave w owns the slots starting at its range start;
+// in-wave order by ballot prefix).  Returns the total; sh.wave_cnt/wave_start
+// describe the four segments.
+__device__ __forceinline__ int scan_hits(const double* __restrict__ x, const double* __restrict__ y, int n, double qx,
+                                         double qy, double thr, int32_t* __restrict__ hits, Sh& sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
+  const int ws = w * per;
+  const int we = ws + per;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int cnt = 0;
+  for (int base = ws; base < we && base < n; base += WAVE_STRIDE) {
+    double2 xv[UNROLL], yv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 128 + lane * 2;
+      xv[u] = *reinterpret_cast<const double2*>(x + i0);
+      yv[u] = *reinterpret_cast<const double2*>(y + i0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 128 + lane * 2;
+      double dx0 = xv[u].x - qx, dy0 = yv[u].x - qy;
+      double dx1 = xv[u].y - qx, dy1 = yv[u].y - qy;
+      bool h0 = (dx0 * dx0 + dy0 * dy0) <= thr;
+      bool h1 = (dx1 * dx1 + dy1 * dy1) <= thr;
+      uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+      if ((m0 | m1) != 0ull) {
+        int pos = cnt + __popcll(m0 & lt_mask) + __popcll(m1 & lt_mask);
+        if (h0) hits[ws + pos] = i0;
+        if (h1) hits[ws + pos + (h0 ? 1 : 0)] = i0 + 1;
+        cnt += __popcll(m0) + __popcll(m1);
+      }
+    }
+  }
+  if (lane == 0) {
+    sh.wave_cnt[w] = cnt;
+    sh.wave_start[w] = ws;
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
+  return total;
+}
+
+// h-th hit of the (virtual) concatenated, ascending list
+__device__ __forceinline__ int hit_at(const int32_t* hits, const Sh& sh, int h) {
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < NW - 1; j++) {
+    if (k == j && h >= sh.wave_cnt[j]) {
+      h -= sh.wave_cnt[j];
+      k = j + 1;
+    }
+  }
+  return hits[sh.wave_start[k] + h];
+}
+
+// ---------------------------------------------------------------------------
+// Exact re-check + the `[lst.index(v) for v in lst if v <= thr]` idiom
+// (rrt_04:1337, :1288-1291): every hit whose EXACT value passes reports the first
+// index holding an equal value, so the distinct indices are the hits that are the
+// first holder of their value, ascending.  mode 0: value = dx**2+dy**2 about
+// (qx,qy); mode 1: value = math.hypot(x-qx, y-qy).
+// Out: sh.uidx/uval[0..nu), sh.nu, sh.nvalid (= len of the reference's list).
+__device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const double* __restrict__ y, double qx,
+                                            double qy, double thr_exact, int mode, const int32_t* hits, int kraw,
+                                            Sh& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    sh.nu = 0;
+    sh.nvalid = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < kraw; base += TPB) {
+    const int h = base + tid;
+    int idx = -1;
+    double v = 0.0;
+    bool valid = false;
+    if (h < kraw) {
+      idx = hit_at(hits, sh, h);
+      double dx = x[idx] - qx, dy = y[idx] - qy;
+      v = (mode == 0) ? rpp::py_d2(dx, dy) : rpp::py_hypot(dx, dy);
+      valid = v <= thr_exact;
+    }
+    const int nu = sh.nu;
+    bool cand = valid;
+    if (cand) {
+      for (int u = 0; u < nu; u++) {
+        if (sh.uval[u] == v) {
+          cand = false;
+          break;
+        }
+      }
+    }
+    sh.cval[tid] = v;
+    sh.cflag[tid] = cand ? 1 : 0;
+    __syncthreads();
+    bool first = cand;
+    if (cand) {
+      for (int t = 0; t < tid; t++) {
+        if (sh.cflag[t] && sh.cval[t] == v) {
+          first = false;
+          break;
+        }
+      }
+    }
+    uint64_t mf = __ballot(first), mv = __ballot(valid);
+    // per-wave counts through red_idx (free between reductions)
+    if (lane == 0) {
+      sh.red_idx[w] = __popcll(mf);
+      atomicAdd(&sh.nvalid, __popcll(mv));
+    }
+    __syncthreads();
+    int off = nu;
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+      if (k < w) off += sh.red_idx[k];
+    int tot = nu;
+#pragma unroll
+    for (int k = 0; k < NW; k++) tot += sh.red_idx[k];
+    if (first) {
+      const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      int p = off + __popcll(mf & lt_mask);
+      if (p < NU_MAX) {
+        sh.uval[p] = v;
+        sh.uidx[p] = idx;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (tot > NU_MAX) {
+        sh.overflow = 1;
+        tot = NU_MAX;
+      }
+      sh.nu = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Steer + collision for `ne` edges.  kind 0: node uidx[e] -> (tx,ty) (choose_parent
+// :1265, goal :1295); kind 1: (tx,ty) -> node uidx[e] (rewire :1359).
+// Out per e: sh.uex/uey (edge end), sh.usafe (no collision AND end inside play area).
+__device__ __forceinline__ void eval_edges(const Ctx& c, const double* __restrict__ x, const double* __restrict__ y,
+                                           int ne, int kind, double tx, double ty, Sh& sh) {
+  const int tid = threadIdx.x;
+  for (int base = 0; base < ne; base += EB) {
+    const int nb = (ne - base) < EB ? (ne - base) : EB;
+    if (tid < nb) {
+      const int u = sh.uidx[base + tid];
+      const double ux = x[u], uy = y[u];
+      if (kind == 0)
+        rpp::steer(&sh.edge[tid], ux, uy, tx, ty, rpp::dinf(), c.res);
+      else
+        rpp::steer(&sh.edge[tid], tx, ty, ux, uy, rpp::dinf(), c.res);
+      sh.ecoll[tid] = 0;
+    }
+    __syncthreads();
+    for (int p = tid; p < nb * c.m; p += TPB) {
+      const int e = p / c.m, k = p - e * c.m;
+      if (rpp::edge_hits_obstacle(sh.edge[e], sh.ox[k], sh.oy[k], sh.othr[k])) sh.ecoll[e] = 1;
+    }
+    __syncthreads();
+    if (tid < nb) {
+      const rpp::Edge& e = sh.edge[tid];
+      sh.uex[base + tid] = e.ex;
+      sh.uey[base + tid] = e.ey;
+      sh.usafe[base + tid] = (!sh.ecoll[tid]) && rpp::in_play_area(c.has_play, c.play_area, e.ex, e.ey);
+    }
+    __syncthreads();
+  }
+}
+
+// first minimum of sh.uaux[0..ne) (list order), block-wide
+__device__ __forceinline__ void first_min(int ne, Sh& sh, double& mn, int& sel) {
+  double best = rpp::dinf(), second = rpp::dinf();
+  int bidx = 0x7fffffff;
+  for (int e = threadIdx.x; e < ne; e += TPB) {
+    double d = sh.uaux[e];
+    if (d < best) {
+      best = d;
+      bidx = e;
+    }
+  }
+  double gs;
+  block_argmin(best, bidx, second, sh, mn, sel, gs);
+}
+
+// propagate_cost_to_leaves (rrt_04:1379-1384) from `root`, one lane, explicit stack.
+__device__ inline int propagate(double* __restrict__ x, double* __restrict__ y, double* __restrict__ cost,
+                                const int32_t* __restrict__ first_child, const int32_t* __restrict__ next_sib,
+                                int32_t* __restrict__ stack, int root) {
+  int sp = 0, count = 0;
+  stack[sp++] = root;
+  while (sp) {
+    const int p = stack[--sp];
+    const double cp = cost[p], xp = x[p], yp = y[p];
+    for (int ch = first_child[p]; ch >= 0; ch = next_sib[ch]) {
+      cost[ch] = cp + rpp::py_hypot(x[ch] - xp, y[ch] - yp);  // calc_new_cost :1375-1377
+      stack[sp++] = ch;
+      count++;
+    }
+  }
+  return count;
+}
+
+__device__ inline void link_child(int32_t* parent, int32_t* first_child, int32_t* next_sib, int32_t* prev_sib, int ch,
+                                  int par) {
+  parent[ch] = par;
+  prev_sib[ch] = -1;
+  if (par >= 0) {
+    const int f = first_child[par];
+    next_sib[ch] = f;
+    if (f >= 0) prev_sib[f] = ch;
+    first_child[par] = ch;
+  } else {
+    next_sib[ch] = -1;
+  }
+}
+__device__ inline void unlink_child(int32_t* parent, int32_t* first_child, int32_t* next_sib, int32_t* prev_sib,
+                                    int ch) {
+  const int par = parent[ch];
+  if (par < 0) return;
+  const int pv = prev_sib[ch], nx = next_sib[ch];
+  if (pv >= 0)
+    next_sib[pv] = nx;
+  else
+    first_child[par] = nx;
+  if (nx >= 0) prev_sib[nx] = pv;
+}
+
+// generate_final_course (rrt_04:1117-1125) + get_path_length (:1391-1399), lane 0.
+__device__ inline void write_path(const Ctx& c, Inst* I, const double* x, const double* y, const int32_t* parent,
+                                  int inst, int gi) {
+  double* out = c.path_xy + (int64_t)inst * c.path_cap * 2;
+  int np = 0, trunc = 0;
+  double px = I->goal[0], py = I->goal[1], len = 0.0;
+  out[0] = px;
+  out[1] = py;
+  np = 1;
+  int nd = gi;
+  for (;;) {
+    const double cx = x[nd], cy = y[nd];
+    len += rpp::py_hypot(cx - px, cy - py);
+    if (np < c.path_cap) {
+      out[2 * np] = cx;
+      out[2 * np + 1] = cy;
+    } else {
+      trunc = 1;
+    }
+    np++;
+    px = cx;
+    py = cy;
+    if (parent[nd] < 0) break;
+    nd = parent[nd];
+  }
+  I->path_n = np;
+  I->goal_node = gi;
+  I->status |= 2 | (trunc ? 8 : 0);
+  c.results[inst].path_cost = len;
+}
+
+// search_best_goal_node (rrt_04:1284-1312): returns the goal node index or -1 (block-uniform).
+__device__ __forceinline__ int best_goal_node(const Ctx& c, Inst* I, const double* x, const double* y,
+                                              const double* cost, int32_t* hits, int n, Sh& sh, int64_t& eu,
+                                              int64_t& er) {
+  const double gx = I->goal[0], gy = I->goal[1];
+  const double thr = c.expand_dis * c.expand_dis * (1.0 + FILTER_EPS);
+  const int kraw = scan_hits(x, y, n, gx, gy, thr, hits, sh);
+  exact_dedup(x, y, gx, gy, c.expand_dis, 1, hits, kraw, sh);
+  const int nu = sh.nu;
+  eu += nu;
+  er += sh.nvalid;
+  if (nu == 0) return -1;
+  eval_edges(c, x, y, nu, 0, gx, gy, sh);
+  for (int e = threadIdx.x; e < nu; e += TPB)
+    sh.uaux[e] = sh.usafe[e] ? cost[sh.uidx[e]] + sh.uval[e] : rpp::dinf();  // cost + calc_dist_to_goal :1303-1305
+  __syncthreads();
+  double mn;
+  int sel;
+  first_min(nu, sh, mn, sel);
+  if (!(mn < rpp::dinf())) return -1;
+  return sh.uidx[sel];
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
+  __shared__ Sh sh;
+  const int inst = blockIdx.x;
+  const int tid = threadIdx.x;
+  Inst* I = c.inst + inst;
+  if (I->status & 1) return;  // done
+  const int64_t off = (int64_t)inst * c.stride;
+  double* __restrict__ x = c.x + off;
+  double* __restrict__ y = c.y + off;
+  double* __restrict__ cost = c.cost + off;
+  int32_t* parent = c.parent + off;
+  int32_t* first_child = c.first_child + off;
+  int32_t* next_sib = c.next_sib + off;
+  int32_t* prev_sib = c.prev_sib + off;
+  int32_t* hits = c.hits + off;
+  int32_t* stack = c.stack + off;
+
+  // stage per-instance state and the obstacle tile in LDS
+  for (int i = tid; i < 624; i += TPB) sh.rng.mt[i] = I->rng.mt[i];
+  for (int i = tid; i < c.m; i += TPB) {
+    sh.ox[i] = c.ox[i];
+    sh.oy[i] = c.oy[i];
+    sh.othr[i] = c.othr[i];
+  }
+  if (tid == 0) {
+    sh.rng.pos = I->rng.pos;
+    sh.overflow = 0;
+  }
+  __syncthreads();
+  int n = I->n, it = I->it;
+  const double gx = I->goal[0], gy = I->goal[1];
+  rpp::Sobol sob = I->sobol;
+  int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_pr = 0, s_sn = 0, s_ab = 0, s_ex = 0;
+  int done = 0;
+
+  for (int step = 0; step < iters && it < c.max_iter && !done; step++, it++) {
+    s_iter++;
+    // ---------------- sample (lane 0) rrt_04:1132-1153
+    if (tid == 0) {
+      double rx, ry;
+      if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {
+        if (c.sampler == 1 && c.algo == 1) {
+          double q[2];
+          rpp::sobol_next(&sob, q);
+          rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);
+          ry = c.rand_min + q[1] * (c.rand_max - c.rand_min);
+        } else {
+          rx = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
+          ry = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
+        }
+      } else {
+        rx = gx;
+        ry = gy;
+      }
+      sh.rx = rx;
+      sh.ry = ry;
+    }
+    __syncthreads();
+    const double rx = sh.rx, ry = sh.ry;
+
+    // ---------------- nearest :1197-1202
+    int ni;
+    double gbest, gsecond;
+    scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
+    s_sn += n;
+    s_ab += 16 * (int64_t)n + 24 * (int64_t)c.m;
+    if (gbest != 0.0 && gsecond <= gbest * (1.0 + FILTER_EPS)) {
+      // two candidates inside the filter margin: re-decide with the exact ** 2
+      s_ex++;
+      const int kraw = scan_hits(x, y, n, rx, ry, gbest * (1.0 + FILTER_EPS), hits, sh);
+      double best = rpp::dinf(), second = rpp::dinf();
+      int bidx = 0x7fffffff;
+      for (int h = tid; h < kraw; h += TPB) {
+        const int idx = hit_at(hits, sh, h);
+        const double d = rpp::py_d2(x[idx] - rx, y[idx] - ry);
+        if (d < best || (d == best && idx < bidx)) {
+          best = d;
+          bidx = idx;
+        }
+      }
+      double gb2, gs2;
+      block_argmin(best, bidx, second, sh, gb2, ni, gs2);
+    }
+
+    // ---------------- steer + collision of the extension :1051-1059
+    if (tid == 0) {
+      rpp::steer(&sh.edge[0], x[ni], y[ni], rx, ry, c.expand_dis, c.res);
+      sh.ecoll[0] = 0;
+      sh.nx = sh.edge[0].ex;
+      sh.ny = sh.edge[0].ey;
+      sh.ncost = cost[ni] + rpp::py_hypot(sh.edge[0].ex - x[ni], sh.edge[0].ey - y[ni]);  // :1054-1056
+      sh.flag = rpp::in_play_area(c.has_play, c.play_area, sh.edge[0].ex, sh.edge[0].ey) ? 1 : 0;
+    }
+    __syncthreads();
+    const double nx = sh.nx, ny = sh.ny;
+    const int inplay = sh.flag;
+    if (inplay) {
+      s_eu++;
+      s_er++;
+      for (int k = tid; k < c.m; k += TPB)
+        if (rpp::edge_hits_obstacle(sh.edge[0], sh.ox[k], sh.oy[k], sh.othr[k])) sh.ecoll[0] = 1;
+    }
+    __syncthreads();
+    const int accepted = inplay && !sh.ecoll[0];
+    int nnear = -1;
+
+    if (accepted && c.algo == 0) {
+      // ---- rrt_01:85-96
+      if (tid == 0) {
+        x[n] = nx;
+        y[n] = ny;
+        cost[n] = 0.0;
+        first_child[n] = -1;
+        link_child(parent, first_child, next_sib, prev_sib, n, ni);
+      }
+      n++;
+      s_ab += 28;
+      __syncthreads();
+    }
+    if (c.algo == 0) {
+      // goal test on node_list[-1] (rrt_01:89-96)
+      if (tid == 0) {
+        const int last = n - 1;
+        int ok = 0;
+        if (rpp::py_hypot(x[last] - gx, y[last] - gy) <= c.expand_dis) {
+          rpp::steer(&sh.edge[0], x[last], y[last], gx, gy, c.expand_dis, c.res);
+          ok = 1;
+        }
+        sh.flag = ok;
+        sh.ecoll[0] = 0;
+      }
+      __syncthreads();
+      if (sh.flag) {
+        s_eu++;
+        s_er++;
+        for (int k = tid; k < c.m; k += TPB)
+          if (rpp::edge_hits_obstacle(sh.edge[0], sh.ox[k], sh.oy[k], sh.othr[k])) sh.ecoll[0] = 1;
+        __syncthreads();
+        if (!sh.ecoll[0]) {
+          if (tid == 0) write_path(c, I, x, y, parent, inst, n - 1);
+          done = 1;
+        }
+      }
+      __syncthreads();
+    }
+
+    if (accepted && c.algo == 1) {
+      // ---------------- find_near_nodes :1314-1338
+      const double r2 = c.r2tab[n + 1];
+      const int kraw = scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
+      s_sn += n;
+      exact_dedup(x, y, nx, ny, r2, 0, hits, kraw, sh);
+      const int nu = sh.nu;
+      const int nvalid = sh.nvalid;
+      nnear = nu;
+      s_nh += nvalid;
+      s_nu += nu;
+      s_ab += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
+      // ---------------- choose_parent :1242-1282
+      int have = 0, sel = -1;
+      double min_cost = rpp::dinf();
+      if (nu > 0) {
+        s_eu += nu;
+        s_er += nvalid;
+        eval_edges(c, x, y, nu, 0, nx, ny, sh);
+        for (int e = tid; e < nu; e += TPB) {
+          const int u = sh.uidx[e];
+          sh.uaux[e] = sh.usafe[e] ? cost[u] + rpp::py_hypot(nx - x[u], ny - y[u]) : rpp::dinf();  // :1269
+        }
+        __syncthreads();
+        first_min(nu, sh, min_cost, sel);
+        have = min_cost < rpp::dinf();
+      }
+      if (have) {
+        // new_node = steer(node_list[min_ind], new_node); cost = min_cost  (:1279-1280)
+        const double wx = sh.uex[sel], wy = sh.uey[sel], wcost = min_cost;
+        const int min_ind = sh.uidx[sel];
+        __syncthreads();
+        // ---------------- rewire (before append) :1340-1373
+        s_eu += nu;
+        s_er += nvalid;
+        eval_edges(c, x, y, nu, 1, wx, wy, sh);
+        for (int e = tid; e < nu; e += TPB) {
+          const int u = sh.uidx[e];
+          sh.uaux[e] = wcost + rpp::py_hypot(x[u] - wx, y[u] - wy);  // edge_node.cost :1362
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const int newidx = n;
+          first_child[newidx] = -1;
+          int nrw = 0, npr = 0;
+          for (int e = 0; e < nu; e++) {  // list order; later entries see earlier updates
+            const int u = sh.uidx[e];
+            const double ec = sh.uaux[e];
+            if (sh.usafe[e] && cost[u] > ec) {  // :1366-1368 strict
+              unlink_child(parent, first_child, next_sib, prev_sib, u);
+              x[u] = sh.uex[e];  // node_list[i] = edge_node :1372 (same xy whenever steer snapped)
+              y[u] = sh.uey[e];
+              cost[u] = ec;
+              link_child(parent, first_child, next_sib, prev_sib, u, newidx);
+              nrw++;
+              npr += propagate(x, y, cost, first_child, next_sib, stack, u);  // :1373
+            }
+          }
+          // append :1065
+          x[newidx] = wx;
+          y[newidx] = wy;
+          cost[newidx] = wcost;
+          link_child(parent, first_child, next_sib, prev_sib, newidx, min_ind);
+          sh.flag = nrw;
+          sh.sel = npr;
+        }
+        __syncthreads();
+        s_rw += sh.flag;
+        s_pr += sh.sel;
+        n++;
+      } else {
+        // choose_parent returned None: append the extension as it is (:1066-1067)
+        if (tid == 0) {
+          x[n] = nx;
+          y[n] = ny;
+          cost[n] = sh.ncost;
+          first_child[n] = -1;
+          link_child(parent, first_child, next_sib, prev_sib, n, ni);
+        }
+        n++;
+        __syncthreads();
+      }
+    }
+
+    if (inst == c.trace_inst && tid == 0) {
+      c.tr_rx[it] = rx;
+      c.tr_ry[it] = ry;
+      c.tr_near[it] = ni;
+      c.tr_nn[it] = nnear;
+    }
+
+    // ---------------- early exit :1072-1076
+    if (c.algo == 1 && !c.until_max) {
+      s_sn += n;
+      s_ab += 16 * (int64_t)n;
+      const int gi = best_goal_node(c, I, x, y, cost, hits, n, sh, s_eu, s_er);
+      if (gi >= 0) {
+        if (tid == 0) write_path(c, I, x, y, parent, inst, gi);
+        done = 1;
+      }
+      __syncthreads();
+    }
+    if (sh.overflow) done = 1;
+  }
+
+  // ---------------- after the loop :1078-1084
+  if (!done && it >= c.max_iter) {
+    if (c.algo == 1) {
+      s_sn += n;
+      s_ab += 16 * (int64_t)n;
+      const int gi = best_goal_node(c, I, x, y, cost, hits, n, sh, s_eu, s_er);
+      if (gi >= 0 && tid == 0) write_path(c, I, x, y, parent, inst, gi);
+      __syncthreads();
+    }
+    done = 1;
+  }
+
+  // write back state
+  __syncthreads();
+  for (int i = tid; i < 624; i += TPB) I->rng.mt[i] = sh.rng.mt[i];
+  if (tid == 0) {
+    I->rng.pos = sh.rng.pos;
+    I->sobol = sob;
+    I->n = n;
+    I->it = it;
+    if (done) I->status |= 1;
+    if (sh.overflow) I->status |= 4;
+    I->iterations += s_iter;
+    I->edges_unique += s_eu;
+    I->edges_ref += s_er;
+    I->near_hits += s_nh;
+    I->near_unique += s_nu;
+    I->rewires += s_rw;
+    I->propagated += s_pr;
+    I->scan_nodes += s_sn;
+    I->alg_bytes += s_ab;
+    I->exact_rescans += s_ex;
+    c.results[inst].n_nodes = n;
+    c.results[inst].status = I->status;
+  }
+}
+
+// initialise one instance's arrays: +inf padding, root node (rrt_04:1043)
+__global__ void rrt_init_kernel(Ctx c) {
+  const int inst = blockIdx.y;
+  const int64_t off = (int64_t)inst * c.stride;
+  const double inf = rpp::dinf();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < c.stride; i += (int64_t)gridDim.x * blockDim.x) {
+    c.x[off + i] = inf;
+    c.y[off + i] = inf;
+  }
+}
+__global__ void rrt_root_kernel(Ctx c, int ninst) {
+  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= ninst) return;
+  const int64_t off = (int64_t)inst * c.stride;
+  Inst* I = c.inst + inst;
+  c.x[off] = I->start[0];
+  c.y[off] = I->start[1];
+  c.cost[off] = 0.0;
+  c.parent[off] = -1;
+  c.first_child[off] = -1;
+  c.next_sib[off] = -1;
+  c.prev_sib[off] = -1;
+  I->n = 1;
+  I->it = 0;
+  I->status = 0;
+  I->goal_node = -1;
+  I->path_n = 0;
+  I->sobol.index = 0;
+  I->sobol.lastq[0] = I->sobol.lastq[1] = 0;
+  I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
+  I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = 0;
+  c.results[inst].path_cost = 0.0;
+  c.results[inst].n_nodes = 1;
+  c.results[inst].status = 0;
+}
+
+// parity harness for the arithmetic replicas (rrtx_selftest_math)
+__global__ void selftest_kernel(int op, const double* a, const double* b, double* o, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double r = 0.0;
+  switch (op) {
+    case 0: r = rpp::py_hypot(a[i], b[i]); break;
+    case 1: r = rpp::py_sq(a[i]); break;
+    case 2: r = rpp_glibc_sin(a[i]); break;
+    case 3: r = rpp_glibc_cos(a[i]); break;
+    case 4: r = rpp_glibc_atan2(a[i], b[i]); break;
+    case 5: {
+      rpp::Edge e;
+      rpp::steer(&e, 0.0, 0.0, a[i], b[i], rpp::dinf(), 0.25);
+      r = e.ex;
+    } break;
+    case 6: r = __builtin_sqrt(a[i]); break;
+    case 7: r = a[i] / b[i]; break;
+  }
+  o[i] = r;
+}
+
+}  // namespace rppk

@@ -1,0 +1,474 @@
+// rrtx_api.hip -- host side of the C ABI declared in include/rrtx.h.
+// Owns device memory, uploads parameters / RNG state, launches the planner
+// kernel in bounded chunks of iterations on the handle's HIP stream, and copies
+// results back.  There is no CPU planning path in this library.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtx.h"
+#include "rrt_kernels.hip.h"
+
+using rppk::Ctx;
+using rppk::Inst;
+using rppk::Result;
+
+namespace {
+
+// libm through volatile pointers: the compiler must not fold pow(x, 2.0) into x*x
+// (glibc's pow is not correctly rounded and the reference's `**2` goes through it).
+double (*volatile libm_pow)(double, double) = pow;
+double (*volatile libm_log)(double) = log;
+double (*volatile libm_sqrt)(double) = sqrt;
+
+inline double py_sq_host(double x) {
+  if (x == 0.0) return 0.0;
+  return libm_pow(std::fabs(x), 2.0);
+}
+
+}  // namespace
+
+struct rrtx_handle {
+  rrtx_params p;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  Ctx c;
+  int64_t stride = 0;
+  int n_inst = 0;
+  int m = 0;
+  bool planned = false;
+  std::vector<Inst> host_inst;  // staging for seeds / starts before the first plan
+  std::vector<double> obst;
+  int trace_inst = -1;
+  rrtx_stats stats;
+  std::string err;
+  std::vector<void*> allocs;
+  int chunk_iters = 1024;
+};
+
+#define HIPCHK(h, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return RRTX_E_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+template <class T>
+static int dalloc(rrtx_handle* h, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) {
+    h->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+    return RRTX_E_HIP;
+  }
+  h->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+extern "C" {
+
+int rrtx_abi_version(void) { return RRTX_ABI_VERSION; }
+
+int rrtx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* rrtx_last_error(rrtx_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+void rrtx_destroy(rrtx_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  for (void* q : h->allocs) hipFree(q);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
+  if (!p || !out) return RRTX_E_INVALID;
+  *out = nullptr;
+  if (p->abi_version != RRTX_ABI_VERSION) return RRTX_E_INVALID;
+  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR) return RRTX_E_INVALID;
+  if (p->n_instances < 1 || p->max_iter < 0 || !(p->path_resolution > 0.0) || !(p->expand_dis >= 0.0))
+    return RRTX_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev)
+    return RRTX_E_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return RRTX_E_NO_DEVICE;
+  if (!strstr(prop.gcnArchName, "gfx950") && !getenv("RRTX_ALLOW_ANY_ARCH")) return RRTX_E_NO_DEVICE;
+  rrtx_handle* h = new rrtx_handle();
+  h->p = *p;
+  h->device = p->device;
+  h->n_inst = p->n_instances;
+  memset(&h->stats, 0, sizeof(h->stats));
+  memset(&h->c, 0, sizeof(h->c));
+  if (const char* e = getenv("RRTX_CHUNK_ITERS")) h->chunk_iters = atoi(e) > 0 ? atoi(e) : 1024;
+  *out = h;  // returned even on failure below so the caller can read last_error, then destroy
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCHK(h, hipEventCreate(&h->ev0));
+  HIPCHK(h, hipEventCreate(&h->ev1));
+  // node capacity: start + one node per iteration; padded so each wave's 512-node stride stays inside
+  const int64_t cap = (int64_t)p->max_iter + 2;
+  h->stride = (cap + 511) / 512 * 512 + 2560;
+  const size_t tot = (size_t)h->stride * h->n_inst;
+  Ctx& c = h->c;
+  int rc;
+  if ((rc = dalloc(h, &c.inst, h->n_inst))) return rc;
+  if ((rc = dalloc(h, &c.x, tot))) return rc;
+  if ((rc = dalloc(h, &c.y, tot))) return rc;
+  if ((rc = dalloc(h, &c.cost, tot))) return rc;
+  if ((rc = dalloc(h, &c.parent, tot))) return rc;
+  if ((rc = dalloc(h, &c.first_child, tot))) return rc;
+  if ((rc = dalloc(h, &c.next_sib, tot))) return rc;
+  if ((rc = dalloc(h, &c.prev_sib, tot))) return rc;
+  if ((rc = dalloc(h, &c.hits, tot))) return rc;
+  if ((rc = dalloc(h, &c.stack, tot))) return rc;
+  if ((rc = dalloc(h, &c.results, h->n_inst))) return rc;
+  c.path_cap = (int32_t)(cap + 1 < 8192 ? cap + 1 : 8192);
+  if ((rc = dalloc(h, &c.path_xy, (size_t)h->n_inst * c.path_cap * 2))) return rc;
+  double *dox, *doy, *dothr, *dr2;
+  if ((rc = dalloc(h, &dox, rppk::MAX_OBS))) return rc;
+  if ((rc = dalloc(h, &doy, rppk::MAX_OBS))) return rc;
+  if ((rc = dalloc(h, &dothr, rppk::MAX_OBS))) return rc;
+  if ((rc = dalloc(h, &dr2, (size_t)cap + 2))) return rc;
+  c.ox = dox;
+  c.oy = doy;
+  c.othr = dothr;
+  c.r2tab = dr2;
+  c.m = 0;
+  c.stride = h->stride;
+  c.algo = p->algo;
+  c.sampler = p->sampler;
+  c.goal_sample_rate = p->goal_sample_rate;
+  c.max_iter = p->max_iter;
+  c.has_play = p->has_play_area;
+  c.until_max = p->search_until_max_iter;
+  c.rand_min = p->rand_min;
+  c.rand_max = p->rand_max;
+  c.expand_dis = p->expand_dis;
+  c.res = p->path_resolution;
+  for (int i = 0; i < 4; i++) c.play_area[i] = p->play_area[i];
+  c.trace_inst = -1;
+  // find_near_nodes radius schedule (rrt_04:1329-1334, :1337): r(nnode)**2 with this host's libm,
+  // exactly the expression the reference evaluates per iteration; it depends on nnode only.
+  std::vector<double> r2((size_t)cap + 2, 0.0);
+  for (int64_t nn = 1; nn < cap + 2; nn++) {
+    double r = p->connect_circle_dist * libm_sqrt(libm_log((double)nn) / (double)nn);
+    if (p->expand_dis < r) r = p->expand_dis;
+    r2[nn] = py_sq_host(r);
+  }
+  HIPCHK(h, hipMemcpy(dr2, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
+  // default per-instance state: ctor start/goal, RNG seeded with the instance number
+  h->host_inst.resize(h->n_inst);
+  for (int i = 0; i < h->n_inst; i++) {
+    Inst& I = h->host_inst[i];
+    memset(&I, 0, sizeof(I));
+    rpp::mt_seed_u64(&I.rng, (uint64_t)i);
+    I.start[0] = p->start[0];
+    I.start[1] = p->start[1];
+    I.goal[0] = p->goal[0];
+    I.goal[1] = p->goal[1];
+  }
+  return RRTX_OK;
+}
+
+int rrtx_set_obstacles(rrtx_handle* h, const double* oxyr, int32_t m) {
+  if (!h || m < 0 || (m > 0 && !oxyr)) return RRTX_E_INVALID;
+  if (m > rppk::MAX_OBS) {
+    h->err = "more than 256 obstacles";
+    return RRTX_E_INVALID;
+  }
+  std::vector<double> ox(rppk::MAX_OBS, 0.0), oy(rppk::MAX_OBS, 0.0), th(rppk::MAX_OBS, -1.0);
+  for (int k = 0; k < m; k++) {
+    ox[k] = oxyr[3 * k];
+    oy[k] = oxyr[3 * k + 1];
+    th[k] = py_sq_host(oxyr[3 * k + 2] + h->p.robot_radius);  // (size+robot_radius)**2  rrt_04:1227
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy((void*)h->c.ox, ox.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy((void*)h->c.oy, oy.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy((void*)h->c.othr, th.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice));
+  h->c.m = m;
+  h->m = m;
+  return RRTX_OK;
+}
+
+int rrtx_set_rng_state(rrtx_handle* h, int32_t instance, const uint32_t* mt624, int32_t pos) {
+  if (!h || !mt624 || instance < 0 || instance >= h->n_inst || pos < 0 || pos > 624) return RRTX_E_INVALID;
+  memcpy(h->host_inst[instance].rng.mt, mt624, 624 * 4);
+  h->host_inst[instance].rng.pos = pos;
+  return RRTX_OK;
+}
+
+int rrtx_get_rng_state(rrtx_handle* h, int32_t instance, uint32_t* mt624, int32_t* pos) {
+  if (!h || !mt624 || !pos || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (h->planned) {
+    HIPCHK(h, hipSetDevice(h->device));
+    rpp::MT r;
+    HIPCHK(h, hipMemcpy(&r, &h->c.inst[instance].rng, sizeof(r), hipMemcpyDeviceToHost));
+    memcpy(mt624, r.mt, 624 * 4);
+    *pos = r.pos;
+  } else {
+    memcpy(mt624, h->host_inst[instance].rng.mt, 624 * 4);
+    *pos = h->host_inst[instance].rng.pos;
+  }
+  return RRTX_OK;
+}
+
+int rrtx_seed_instances(rrtx_handle* h, int32_t first, int32_t count, const uint64_t* seeds) {
+  if (!h || !seeds || first < 0 || count < 0 || first + count > h->n_inst) return RRTX_E_INVALID;
+  for (int i = 0; i < count; i++) rpp::mt_seed_u64(&h->host_inst[first + i].rng, seeds[i]);
+  return RRTX_OK;
+}
+
+int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, const double* goal3) {
+  if (!h || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  Inst& I = h->host_inst[instance];
+  if (start3) {
+    I.start[0] = start3[0];
+    I.start[1] = start3[1];
+  }
+  if (goal3) {
+    I.goal[0] = goal3[0];
+    I.goal[1] = goal3[1];
+  }
+  return RRTX_OK;
+}
+
+int rrtx_enable_trace(rrtx_handle* h, int32_t instance) {
+  if (!h || instance < -1 || instance >= h->n_inst) return RRTX_E_INVALID;
+  h->trace_inst = instance;
+  if (instance >= 0 && !h->c.tr_rx) {
+    int rc;
+    const size_t n = (size_t)h->p.max_iter + 1;
+    if ((rc = dalloc(h, &h->c.tr_rx, n))) return rc;
+    if ((rc = dalloc(h, &h->c.tr_ry, n))) return rc;
+    if ((rc = dalloc(h, &h->c.tr_near, n))) return rc;
+    if ((rc = dalloc(h, &h->c.tr_nn, n))) return rc;
+  }
+  h->c.trace_inst = instance;
+  return RRTX_OK;
+}
+
+int rrtx_plan(rrtx_handle* h) {
+  if (!h) return RRTX_E_INVALID;
+  auto t0 = std::chrono::steady_clock::now();
+  HIPCHK(h, hipSetDevice(h->device));
+  Ctx& c = h->c;
+  const int B = h->n_inst;
+  HIPCHK(h, hipMemcpyAsync(c.inst, h->host_inst.data(), sizeof(Inst) * B, hipMemcpyHostToDevice, h->stream));
+  {
+    dim3 g(64, B);
+    hipLaunchKernelGGL(rppk::rrt_init_kernel, g, dim3(256), 0, h->stream, c);
+    hipLaunchKernelGGL(rppk::rrt_root_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, c, B);
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  double kms = 0.0;
+  int64_t launches = 0;
+  std::vector<Result> res(B);
+  for (;;) {
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    kms += ms;
+    launches++;
+    bool all = true;
+    for (int i = 0; i < B; i++)
+      if (!(res[i].status & RRTX_ST_DONE)) {
+        all = false;
+        break;
+      }
+    if (all) break;
+    if (launches > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
+      h->err = "planner kernel did not converge to DONE";
+      return RRTX_E_STATE;
+    }
+  }
+  // aggregate counters
+  std::vector<Inst> back(B);
+  HIPCHK(h, hipMemcpy(back.data(), c.inst, sizeof(Inst) * B, hipMemcpyDeviceToHost));
+  rrtx_stats& s = h->stats;
+  memset(&s, 0, sizeof(s));
+  bool overflow = false;
+  for (int i = 0; i < B; i++) {
+    const Inst& I = back[i];
+    s.iterations += I.iterations;
+    s.edges_unique += I.edges_unique;
+    s.edges_ref += I.edges_ref;
+    s.near_hits += I.near_hits;
+    s.near_unique += I.near_unique;
+    s.rewires += I.rewires;
+    s.propagated += I.propagated;
+    s.scan_nodes += I.scan_nodes;
+    s.algorithmic_bytes += I.alg_bytes;
+    s.exact_rescans += I.exact_rescans;
+    s.total_nodes += I.n;
+    if (I.status & RRTX_ST_OVERFLOW) overflow = true;
+  }
+  s.launches = launches;
+  s.kernel_ms = kms;
+  s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  h->planned = true;
+  if (overflow) {
+    h->err = "near-candidate list exceeded its on-device capacity (NU_MAX)";
+    return RRTX_E_OVERFLOW;
+  }
+  return RRTX_OK;
+}
+
+int rrtx_get_tree(rrtx_handle* h, int32_t instance, double* x, double* y, double* cost, int32_t* parent, int32_t cap,
+                  int32_t* n_out) {
+  if (!h || instance < 0 || instance >= h->n_inst || !n_out) return RRTX_E_INVALID;
+  if (!h->planned) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Result r;
+  HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));
+  *n_out = r.n_nodes;
+  if ((x || y || cost || parent) && cap < r.n_nodes) return RRTX_E_CAPACITY;
+  const int64_t off = (int64_t)instance * h->stride;
+  if (x) HIPCHK(h, hipMemcpy(x, h->c.x + off, sizeof(double) * r.n_nodes, hipMemcpyDeviceToHost));
+  if (y) HIPCHK(h, hipMemcpy(y, h->c.y + off, sizeof(double) * r.n_nodes, hipMemcpyDeviceToHost));
+  if (cost) HIPCHK(h, hipMemcpy(cost, h->c.cost + off, sizeof(double) * r.n_nodes, hipMemcpyDeviceToHost));
+  if (parent) HIPCHK(h, hipMemcpy(parent, h->c.parent + off, sizeof(int32_t) * r.n_nodes, hipMemcpyDeviceToHost));
+  return RRTX_OK;
+}
+
+int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_points, int32_t* n_out) {
+  if (!h || instance < 0 || instance >= h->n_inst || !n_out) return RRTX_E_INVALID;
+  if (!h->planned) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Inst I;
+  HIPCHK(h, hipMemcpy(&I, h->c.inst + instance, sizeof(I), hipMemcpyDeviceToHost));
+  if (!(I.status & RRTX_ST_PATH)) {
+    *n_out = 0;
+    return RRTX_OK;
+  }
+  *n_out = I.path_n;
+  if (!xy) return RRTX_OK;
+  if (cap_points < I.path_n) return RRTX_E_CAPACITY;
+  if (!(I.status & RRTX_ST_PATH_TRUNC)) {
+    HIPCHK(h, hipMemcpy(xy, h->c.path_xy + (int64_t)instance * h->c.path_cap * 2, sizeof(double) * 2 * I.path_n,
+                        hipMemcpyDeviceToHost));
+    return RRTX_OK;
+  }
+  // deeper than the on-device path buffer: walk the parent array on the host (rrt_04:1117-1125)
+  const int n = I.n;
+  std::vector<double> x(n), y(n);
+  std::vector<int32_t> par(n);
+  const int64_t off = (int64_t)instance * h->stride;
+  HIPCHK(h, hipMemcpy(x.data(), h->c.x + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(y.data(), h->c.y + off, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(par.data(), h->c.parent + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  int k = 0;
+  xy[0] = I.goal[0];
+  xy[1] = I.goal[1];
+  k = 1;
+  for (int nd = I.goal_node;; nd = par[nd]) {
+    xy[2 * k] = x[nd];
+    xy[2 * k + 1] = y[nd];
+    k++;
+    if (par[nd] < 0) break;
+  }
+  return RRTX_OK;
+}
+
+int rrtx_get_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status) {
+  if (!h) return RRTX_E_INVALID;
+  if (!h->planned) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<Result> r(h->n_inst);
+  HIPCHK(h, hipMemcpy(r.data(), h->c.results, sizeof(Result) * h->n_inst, hipMemcpyDeviceToHost));
+  for (int i = 0; i < h->n_inst; i++) {
+    if (path_cost) path_cost[i] = (r[i].status & RRTX_ST_PATH) ? r[i].path_cost : INFINITY;
+    if (n_nodes) n_nodes[i] = r[i].n_nodes;
+    if (status) status[i] = r[i].status;
+  }
+  return RRTX_OK;
+}
+
+int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes) {
+  if (!h || !dptr || !bytes) return RRTX_E_INVALID;
+  *dptr = (void*)h->c.results;
+  *bytes = (int64_t)sizeof(Result) * h->n_inst;
+  return RRTX_OK;
+}
+
+int rrtx_get_sobol_index(rrtx_handle* h, int32_t instance, int64_t* index) {
+  if (!h || !index || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (!h->planned) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  rpp::Sobol s;
+  HIPCHK(h, hipMemcpy(&s, &h->c.inst[instance].sobol, sizeof(s), hipMemcpyDeviceToHost));
+  *index = s.index;
+  return RRTX_OK;
+}
+
+int rrtx_get_stats(rrtx_handle* h, rrtx_stats* st) {
+  if (!h || !st) return RRTX_E_INVALID;
+  *st = h->stats;
+  return RRTX_OK;
+}
+
+int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* nearest, int32_t* n_near, int32_t cap,
+                   int32_t* n_out) {
+  if (!h || !n_out) return RRTX_E_INVALID;
+  if (!h->planned || h->trace_inst < 0) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Inst I;
+  HIPCHK(h, hipMemcpy(&I, h->c.inst + h->trace_inst, sizeof(I), hipMemcpyDeviceToHost));
+  const int n = I.it;
+  *n_out = n;
+  if (cap < n) return RRTX_E_CAPACITY;
+  if (rnd_x) HIPCHK(h, hipMemcpy(rnd_x, h->c.tr_rx, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (rnd_y) HIPCHK(h, hipMemcpy(rnd_y, h->c.tr_ry, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (nearest) HIPCHK(h, hipMemcpy(nearest, h->c.tr_near, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  if (n_near) HIPCHK(h, hipMemcpy(n_near, h->c.tr_nn, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return RRTX_OK;
+}
+
+int rrtx_selftest_math(int32_t device, int32_t op, const double* a, const double* b, double* out, int64_t n) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return RRTX_E_NO_DEVICE;
+  if (!a || !b || !out || n < 0) return RRTX_E_INVALID;
+  if (hipSetDevice(device) != hipSuccess) return RRTX_E_HIP;
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  int rc = RRTX_OK;
+  if (hipMalloc(&da, n * 8) != hipSuccess || hipMalloc(&db, n * 8) != hipSuccess ||
+      hipMalloc(&dout, n * 8) != hipSuccess)
+    rc = RRTX_E_HIP;
+  if (!rc && (hipMemcpy(da, a, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+              hipMemcpy(db, b, n * 8, hipMemcpyHostToDevice) != hipSuccess))
+    rc = RRTX_E_HIP;
+  if (!rc) {
+    hipLaunchKernelGGL(rppk::selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, op, da, db, dout, n);
+    if (hipDeviceSynchronize() != hipSuccess) rc = RRTX_E_HIP;
+  }
+  if (!rc && hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = RRTX_E_HIP;
+  hipFree(da);
+  hipFree(db);
+  hipFree(dout);
+  return rc;
+}
+
+}  // extern "C"

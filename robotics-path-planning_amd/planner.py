@@ -1,0 +1,287 @@
+"""Host-side mirrors of the reference planner classes, driving the HIP library.
+
+Same constructor keywords, entry points, attributes and return shapes as
+  rrt_01: /root/reference/src_path_planning/10_path_planning_01_rrt_01_simple.py   class RRT :16-101
+  rrt_04: /root/reference/src_path_planning/10_path_planning_01_rrt_04_rrt_star.py class RRT :932-1384
+so a driver script written against the reference runs unchanged:
+
+    random.seed(s)
+    rrt = RRT(start=..., goal=..., obstacle_list=..., rand_area=..., ...)
+    path = rrt.planning(animation=False)      # list of [x, y] goal -> start, or None
+    len(rrt.node_list); rrt.node_list[i].path_x; rrt.draw_graph()
+
+`planning()` hands CPython's global `random` state to the device (the kernels
+consume the MT19937 stream exactly as random.randint / random.uniform would) and
+stores the advanced state back, so code after the call sees the same stream it
+would have seen with the reference.  stdout chatter of the reference
+("Iter: ...", rrt_04:1045) is not reproduced.  All planning runs on the GPU.
+"""
+import math
+import random
+
+import numpy as np
+
+from . import _abi
+
+
+class Node:
+    """RRT.Node (rrt_04:933-942); path_x/path_y are rebuilt on demand for drawing."""
+
+    def __init__(self, x, y):
+        self.x = x
+        self.y = y
+        self.path_x = []
+        self.path_y = []
+        self.parent = None
+        self.cost = 0.0
+
+
+class AreaBounds:
+    """RRT.AreaBounds (rrt_04:944-949)."""
+
+    def __init__(self, area):
+        self.xmin = float(area[0])
+        self.xmax = float(area[1])
+        self.ymin = float(area[2])
+        self.ymax = float(area[3])
+
+
+def _steer_polyline(fx, fy, tx, ty, extend, res):
+    """Polyline of steer() (rrt_04:1086-1115) with CPython's own math, for path_x/path_y."""
+    nx, ny = fx, fy
+    dx, dy = tx - nx, ty - ny
+    d, theta = math.hypot(dx, dy), math.atan2(dy, dx)
+    px, py = [nx], [ny]
+    if extend > d:
+        extend = d
+    for _ in range(math.floor(extend / res)):
+        nx += res * math.cos(theta)
+        ny += res * math.sin(theta)
+        px.append(nx)
+        py.append(ny)
+    if math.hypot(tx - nx, ty - ny) <= res:
+        px.append(tx)
+        py.append(ty)
+    return px, py
+
+
+class NodeList:
+    """Lazy `node_list`: SoA arrays from the device, Node objects made on access.
+
+    Parents are object references as in rrt_01/rrt_04 (the same Node object is
+    returned for the same index, so identity comparisons behave)."""
+
+    def __init__(self, x, y, cost, parent, res):
+        self._x, self._y, self._cost, self._parent, self._res = x, y, cost, parent, res
+        self._cache = {}
+
+    def __len__(self):
+        return len(self._x)
+
+    def _make(self, i):
+        nd = self._cache.get(i)
+        if nd is not None:
+            return nd
+        # iterative parent chain construction (trees are ~100 deep, but avoid recursion limits)
+        chain = []
+        j = i
+        while j >= 0 and j not in self._cache:
+            chain.append(j)
+            j = int(self._parent[j])
+        for j in reversed(chain):
+            n = Node(float(self._x[j]), float(self._y[j]))
+            n.cost = float(self._cost[j])
+            pj = int(self._parent[j])
+            if pj >= 0:
+                par = self._cache[pj]
+                n.parent = par
+                n.path_x, n.path_y = _steer_polyline(par.x, par.y, n.x, n.y, float("inf"), self._res)
+            self._cache[j] = n
+        return self._cache[i]
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._make(j) for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        return self._make(i)
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self._make(i)
+
+
+class _PlannerBase:
+    Node = Node
+    AreaBounds = AreaBounds
+    _ALGO = None
+
+    def _common_init(self, start, goal, obstacle_list, rand_area, expand_dis, path_resolution, goal_sample_rate,
+                     max_iter, play_area, robot_radius, device):
+        self.start = Node(start[0], start[1])
+        self.end = Node(goal[0], goal[1])
+        self.min_rand = rand_area[0]
+        self.max_rand = rand_area[1]
+        self.play_area = AreaBounds(play_area) if play_area is not None else None
+        self._play_area_arg = play_area
+        self.expand_dis = expand_dis
+        self.path_resolution = path_resolution
+        self.goal_sample_rate = goal_sample_rate
+        self.max_iter = max_iter
+        self.obstacle_list = obstacle_list
+        self.node_list = []
+        self.robot_radius = robot_radius
+        self.device = device
+        self.stats = None
+        self._trace = False
+        self.trace = None
+
+    def _run(self, sampler, ccd, until_max):
+        h = _abi.Handle(self._ALGO, [self.start.x, self.start.y], [self.end.x, self.end.y],
+                        [self.min_rand, self.max_rand], self.expand_dis, self.path_resolution, self.goal_sample_rate,
+                        self.max_iter, play_area=self._play_area_arg, robot_radius=self.robot_radius, sampler=sampler,
+                        connect_circle_dist=ccd, search_until_max_iter=until_max, n_instances=1, device=self.device)
+        try:
+            h.set_obstacles(self.obstacle_list)
+            st = random.getstate()
+            h.set_rng_state(0, st)
+            if self._trace:
+                h.enable_trace(0)
+            h.plan()
+            random.setstate(h.get_rng_state(0, st[2]))
+            x, y, cost, parent = h.get_tree(0)
+            self.node_list = NodeList(x, y, cost, parent, self.path_resolution)
+            self.tree = (x, y, cost, parent)
+            path = h.get_path(0)
+            self.stats = h.get_stats()
+            if self._trace:
+                self.trace = h.get_trace()
+            if sampler == _abi.SAMPLER_SOBOL:
+                self.sobol_inter_ = h.get_sobol_index(0)
+        finally:
+            h.close()
+        if path is None:
+            return None
+        return [[float(px), float(py)] for px, py in path]
+
+    # drawing helpers of the reference (rrt_04:1155-1194); animation happens after the fact
+    def draw_graph(self, rnd=None):  # pragma: no cover
+        import matplotlib.pyplot as plt
+        plt.clf()
+        if rnd is not None:
+            plt.plot(rnd.x, rnd.y, "^k")
+        for node in self.node_list:
+            if node.parent:
+                plt.plot(node.path_x, node.path_y, "-g")
+        for (ox, oy, size) in self.obstacle_list:
+            self.plot_circle(ox, oy, size)
+        if self.play_area is not None:
+            pa = self.play_area
+            plt.plot([pa.xmin, pa.xmax, pa.xmax, pa.xmin, pa.xmin], [pa.ymin, pa.ymin, pa.ymax, pa.ymax, pa.ymin], "-k")
+        plt.plot(self.start.x, self.start.y, "xr")
+        plt.plot(self.end.x, self.end.y, "xr")
+        plt.axis("equal")
+        plt.grid(True)
+
+    @staticmethod
+    def plot_circle(x, y, size, color="-b"):  # pragma: no cover
+        import matplotlib.pyplot as plt
+        deg = list(range(0, 360, 5)) + [0]
+        plt.plot([x + size * math.cos(np.deg2rad(d)) for d in deg],
+                 [y + size * math.sin(np.deg2rad(d)) for d in deg], color)
+
+    def calc_dist_to_goal(self, x, y):
+        return math.hypot(x - self.end.x, y - self.end.y)
+
+
+class RRT(_PlannerBase):
+    """Drop-in for rrt_01's `RRT` (10_path_planning_01_rrt_01_simple.py:16-101)."""
+    _ALGO = _abi.ALGO_RRT
+
+    def __init__(self, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
+                 goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, device=0):
+        self._common_init(start, goal, obstacle_list, rand_area, expand_dis, path_resolution, goal_sample_rate,
+                          max_iter, play_area, robot_radius, device)
+
+    def planning(self, animation=True):
+        path = self._run(_abi.SAMPLER_MT, 50.0, False)
+        if animation:  # pragma: no cover
+            self.draw_graph()
+        return path
+
+    plan = planning
+
+
+class RRTStar(_PlannerBase):
+    """Drop-in for rrt_04's `RRT` (10_path_planning_01_rrt_04_rrt_star.py:932-1384)."""
+    _ALGO = _abi.ALGO_RRT_STAR
+
+    def __init__(self, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
+                 goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=True,
+                 connect_circle_dist=50.0, search_until_max_iter=False, device=0):
+        self._common_init(start, goal, obstacle_list, rand_area, expand_dis, path_resolution, goal_sample_rate,
+                          max_iter, play_area, robot_radius, device)
+        self.sobol_sampler = sobol_sampler
+        self.sobol_inter_ = 0
+        self.connect_circle_dist = connect_circle_dist
+        self.goal_node = Node(goal[0], goal[1])
+        self.search_until_max_iter = search_until_max_iter
+
+    def planning(self, animation=True):
+        path = self._run(_abi.SAMPLER_SOBOL if self.sobol_sampler else _abi.SAMPLER_MT, self.connect_circle_dist,
+                         self.search_until_max_iter)
+        if animation:  # pragma: no cover
+            self.draw_graph()
+        return path
+
+    plan = planning
+
+
+def get_path_length(path):
+    """rrt_04:1391-1399."""
+    le = 0
+    for i in range(len(path) - 1):
+        le += math.hypot(path[i + 1][0] - path[i][0], path[i + 1][1] - path[i][1])
+    return le
+
+
+class BatchPlanner:
+    """Many independent planning instances (seeds / start-goal pairs) on one GPU.
+
+    This is the throughput form of the same kernels: instance i consumes the stream of
+    `random.seed(seeds[i])` and produces exactly the tree the single-instance class would.
+    """
+
+    def __init__(self, algo, seeds, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
+                 goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=False,
+                 connect_circle_dist=50.0, search_until_max_iter=False, device=0, starts=None, goals=None):
+        a = {"rrt": _abi.ALGO_RRT, "rrt_star": _abi.ALGO_RRT_STAR}[algo]
+        self.seeds = list(seeds)
+        self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
+                             play_area=play_area, robot_radius=robot_radius,
+                             sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT,
+                             connect_circle_dist=connect_circle_dist, search_until_max_iter=search_until_max_iter,
+                             n_instances=len(self.seeds), device=device)
+        self.h.set_obstacles(obstacle_list)
+        self.h.seed_instances(self.seeds)
+        if starts is not None or goals is not None:
+            for i in range(len(self.seeds)):
+                self.h.set_instance(i, None if starts is None else starts[i], None if goals is None else goals[i])
+
+    def plan(self):
+        self.h.plan()
+        return self.h.get_results()
+
+    def stats(self):
+        return self.h.get_stats()
+
+    def tree(self, i):
+        return self.h.get_tree(i)
+
+    def path(self, i):
+        return self.h.get_path(i)
+
+    def close(self):
+        self.h.close()

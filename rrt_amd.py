@@ -1,0 +1,17 @@
+"""Importable alias of the `robotics-path-planning_amd` package (hyphenated directory name)."""
+import importlib
+import os
+import sys
+
+_root = os.path.dirname(os.path.abspath(__file__))
+if _root not in sys.path:
+    sys.path.insert(0, _root)
+_pkg = importlib.import_module("robotics-path-planning_amd")
+_abi = _pkg._abi
+planner = importlib.import_module("robotics-path-planning_amd.planner")
+RRT = _pkg.RRT
+RRTStar = _pkg.RRTStar
+BatchPlanner = _pkg.BatchPlanner
+Node = _pkg.Node
+AreaBounds = _pkg.AreaBounds
+get_path_length = _pkg.get_path_length

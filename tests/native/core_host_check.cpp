@@ -1,0 +1,88 @@
+// Host unit test of robotics-path-planning_amd/csrc/rpp_core.h (the scalar core the
+// HIP kernels are built from) against the CPU oracle: steer end point / snap
+// decision / polyline collision, hypot, **2, Sobol and MT19937.
+// Built and run by tests/test_core_host.py (CPU only, no GPU).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <dlfcn.h>
+#include "rpp_core.h"
+
+static uint64_t s = 0x9E3779B97F4A7C15ULL;
+static inline uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+static inline double u01() { return (rnd() >> 11) * (1.0 / 9007199254740992.0); }
+
+typedef int (*steer_fn)(double, double, double, double, double, double, double*, double*, int, double*, int*);
+typedef double (*d2_fn)(double, double);
+typedef double (*d1_fn)(double);
+typedef void (*sob_fn)(int, double*);
+struct OMT { uint32_t mt[624]; int32_t pos; };
+typedef void (*seed_fn)(OMT*, uint64_t);
+typedef uint32_t (*next_fn)(OMT*);
+
+int main(int argc, char** argv) {
+  if (argc < 3) { fprintf(stderr, "usage: %s liboracle.so N\n", argv[0]); return 2; }
+  void* h = dlopen(argv[1], RTLD_NOW);
+  if (!h) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+  steer_fn osteer = (steer_fn)dlsym(h, "orc_steer_polyline");
+  d2_fn ohyp = (d2_fn)dlsym(h, "orc_hypot");
+  d1_fn osq = (d1_fn)dlsym(h, "orc_sq");
+  sob_fn osob = (sob_fn)dlsym(h, "orc_sobol_points");
+  seed_fn oseed = (seed_fn)dlsym(h, "orc_mt_seed");
+  next_fn onext = (next_fn)dlsym(h, "orc_mt_next");
+  long N = atol(argv[2]);
+  long bad = 0;
+  // hypot, **2
+  for (long i = 0; i < N * 10; i++) {
+    double a = (u01() * 2 - 1) * 120, b = (u01() * 2 - 1) * 120;
+    if (i % 7 == 0) a *= 1e-3;
+    if (i % 11 == 0) b *= 1e-9;
+    if (i % 1013 == 0) a = 0;
+    if (i % 1019 == 0) b = 0;
+    double x = rpp::py_hypot(a, b), y = ohyp(a, b);
+    if (memcmp(&x, &y, 8)) { if (bad++ < 5) printf("hypot %a %a: %a vs %a\n", a, b, x, y); }
+    x = rpp::py_sq(a); y = osq(a);
+    if (memcmp(&x, &y, 8)) { if (bad++ < 5) printf("sq %a: %a vs %a\n", a, x, y); }
+  }
+  // steer + collision
+  double px[256], py[256];
+  for (long i = 0; i < N; i++) {
+    double res = (i & 1) ? 0.25 : 0.1, ext = (i & 1) ? 2.0 : 1.0;
+    if (i % 3 == 0) ext = INFINITY;
+    double fx = u01() * 100, fy = u01() * 100;
+    double len = u01() * 2.5;
+    if (i % 5 == 0) len = 2.0;      // constructed near-ties: a multiple of the resolution
+    if (i % 17 == 0) len = 0.0;     // duplicate node
+    double th = (u01() * 2 - 1) * 3.141592653589793;
+    double tx = fx + len * cos(th), ty = fy + len * sin(th);
+    if (i % 5 == 0) { // target produced by an actual 8-step extension, like choose_parent sees it
+      rpp::Edge e0; rpp::steer(&e0, fx, fy, fx + 5 * cos(th), fy + 5 * sin(th), ext == INFINITY ? 2.0 : ext, res);
+      tx = e0.ex; ty = e0.ey; ext = INFINITY;
+    }
+    rpp::Edge e; rpp::steer(&e, fx, fy, tx, ty, ext, res);
+    double end[2]; int sn;
+    int np = osteer(fx, fy, tx, ty, ext, res, px, py, 256, end, &sn);
+    if (memcmp(&e.ex, &end[0], 8) || memcmp(&e.ey, &end[1], 8) || sn != e.snapped || np != 1 + e.n_expand + e.snapped) {
+      if (bad++ < 5) printf("steer mismatch i=%ld: (%a,%a) vs (%a,%a) np %d vs %d\n", i, e.ex, e.ey, end[0], end[1], 1 + e.n_expand + e.snapped, np);
+      continue;
+    }
+    for (int k = 0; k < 8; k++) {
+      double ox = fx + (u01() * 2 - 1) * 3, oy = fy + (u01() * 2 - 1) * 3, r = 0.3 + u01() * 1.5;
+      double thr = rpp::py_sq(r);
+      bool hit = rpp::edge_hits_obstacle(e, ox, oy, thr);
+      double mn = INFINITY;
+      for (int j = 0; j < np; j++) { double dx = ox - px[j], dy = oy - py[j]; double d = dx * dx + dy * dy; if (d < mn) mn = d; }
+      if (hit != (mn <= thr)) { if (bad++ < 5) printf("collision mismatch i=%ld\n", i); }
+    }
+  }
+  // Sobol
+  { const int n = 5000; double* a = (double*)malloc(16 * n); osob(n, a); rpp::Sobol sb; sb.index = 0; sb.lastq[0] = sb.lastq[1] = 0;
+    for (int i = 0; i < n; i++) { double q[2]; rpp::sobol_next(&sb, q); if (q[0] != a[2 * i] || q[1] != a[2 * i + 1]) { if (bad++ < 5) printf("sobol %d\n", i); } }
+    free(a); }
+  // MT19937
+  { OMT o; rpp::MT m; oseed(&o, 1234); rpp::mt_seed_u64(&m, 1234);
+    for (int i = 0; i < 5000; i++) { uint32_t a = onext(&o), b = rpp::mt_next(&m); if (a != b) { if (bad++ < 5) printf("mt %d\n", i); } } }
+  printf("core_host_check: N=%ld mismatches=%ld\n", N, bad);
+  return bad ? 1 : 0;
+}

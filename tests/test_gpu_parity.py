@@ -1,0 +1,171 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the golden vectors generated from the
+reference and against the CPU oracle on the same seeded inputs.  Integer arrays bit-exact; doubles are
+compared bit-exact as well (stronger than the 1e-6 the contract asks for)."""
+import math
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_arithmetic_replicas(gpu):
+    """hypot / **2 / sin / cos / atan2 / steer / sqrt / division on the device == CPython+glibc on the host."""
+    import oracle
+    import rrt_amd
+    L = oracle.lib()
+    rng = np.random.default_rng(7)
+    n = 200000
+    a = (rng.random(n) * 2 - 1) * 120
+    b = (rng.random(n) * 2 - 1) * 120
+    a[::7] *= 1e-3
+    b[::11] *= 1e-6
+    a[::1013] = 0.0
+    th = (rng.random(n) * 2 - 1) * 3.2
+    sel = rrt_amd._abi.selftest_math
+    got = sel(0, a, b)
+    assert all(got[i] == math.hypot(a[i], b[i]) for i in range(n)), "hypot"
+    got = sel(1, a, b)
+    assert all(got[i] == (a[i] ** 2) for i in range(n)), "**2"
+    got = sel(2, th, b)
+    assert all(got[i] == math.sin(th[i]) for i in range(n)), "sin"
+    got = sel(3, th, b)
+    assert all(got[i] == math.cos(th[i]) for i in range(n)), "cos"
+    got = sel(4, a, b)
+    assert all(got[i] == math.atan2(a[i], b[i]) for i in range(n)), "atan2"
+    got = sel(6, np.abs(a), b)
+    assert all(got[i] == math.sqrt(abs(a[i])) for i in range(n)), "sqrt"
+    bb = np.where(b == 0, 1.0, b)
+    got = sel(7, a, bb)
+    assert np.array_equal(got, a / bb), "division"
+    # steer end point (constructed near-ties included): (0,0) -> (a,b) scaled to length ~2.0
+    ang = th
+    tx = 2.0 * np.cos(ang)
+    ty = 2.0 * np.sin(ang)
+    got = sel(5, tx, ty)
+    import ctypes as C
+    end = (C.c_double * 2)()
+    sn = C.c_int()
+    px = (C.c_double * 64)()
+    py = (C.c_double * 64)()
+    L.orc_steer_polyline.argtypes = [C.c_double] * 6 + [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for i in range(0, n, 10):
+        L.orc_steer_polyline(0.0, 0.0, tx[i], ty[i], float("inf"), 0.25, px, py, 64, end, C.byref(sn))
+        assert got[i] == end[0], i
+
+
+def _check_against_golden(g, out, i=0):
+    kw = util.kwargs_from_golden(g)
+    util.assert_tree_equal(out["trees"][i], (g["x"], g["y"], g["cost"] if kw["algo"] == "rrt_star" else None,
+                                             g["parent"]), g["name"])
+    p = out["paths"][i]
+    if len(g["path"]) == 0:
+        assert p is None
+    else:
+        assert p is not None and np.array_equal(p, g["path"])
+    st = out["rng"][i]
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
+@pytest.mark.parametrize("path", util.golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_matches_reference_golden(gpu, path):
+    g = util.load_golden(path)
+    kw = util.kwargs_from_golden(g)
+    out = util.run_gpu_batch(kw, [int(g["seed"])], trace_instance=0)
+    d = util.first_trace_divergence(out["trace"], g["tr_rnd_x"], g["tr_rnd_y"], g["tr_nearest"])
+    assert d is None, "first divergent iteration %d" % d
+    _check_against_golden(g, out)
+    assert out["stats"]["edges_ref"] == int(g["ref_edges"])
+    if kw["sobol"]:
+        assert out["sobol_index"][0] == int(g["sobol_index_after"])
+
+
+def test_gpu_batch_equals_oracle_per_seed(gpu):
+    """Many instances in one launch: instance i == oracle(seed i), independent of its neighbours."""
+    kw = util.c2_kwargs(1500)
+    seeds = list(range(1, 41))
+    out = util.run_gpu_batch(kw, seeds)
+    pc, nn, st = out["results"]
+    for i, s in enumerate(seeds):
+        r = util.run_oracle(kw, s, exact_pow=True)
+        util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % s)
+        if r["path"] is None:
+            assert out["paths"][i] is None and math.isinf(pc[i])
+        else:
+            assert np.array_equal(out["paths"][i], r["path"])
+            le = 0.0
+            for j in range(len(r["path"]) - 1):
+                le += math.hypot(r["path"][j + 1][0] - r["path"][j][0], r["path"][j + 1][1] - r["path"][j][1])
+            assert pc[i] == le
+        assert nn[i] == len(r["x"])
+    agg = out["stats"]
+    assert agg["total_nodes"] == int(nn.sum())
+
+
+def test_gpu_stats_match_oracle_counters(gpu):
+    kw = util.c2_kwargs(3000)
+    out = util.run_gpu_batch(kw, [5])
+    r = util.run_oracle(kw, 5, exact_pow=True)
+    s, o = out["stats"], r["stats"]
+    for k in ("edges_ref", "edges_unique", "near_hits", "near_unique", "rewires", "propagated", "iterations"):
+        assert s[k] == o[k], k
+
+
+def test_gpu_c2_20k_nodes_equals_oracle(gpu):
+    """Well past the reference-feasible size: GPU vs the (golden-pinned) oracle, 20 000 iterations."""
+    kw = util.c2_kwargs(20000)
+    out = util.run_gpu_batch(kw, [1, 2])
+    for i, s in enumerate([1, 2]):
+        r = util.run_oracle(kw, s, exact_pow=False)
+        util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % s)
+        assert np.array_equal(out["paths"][i], r["path"])
+
+
+def test_size_independent_invariants(gpu):
+    """Properties that hold at any size: tree consistency after planning."""
+    kw = util.c2_kwargs(6000)
+    out = util.run_gpu_batch(kw, [11])
+    x, y, cost, parent = out["trees"][0]
+    assert parent[0] == -1 and (parent[1:] >= 0).all() and (parent[1:] < len(x)).all()
+    for i in range(1, len(x)):
+        p = parent[i]
+        assert cost[i] == cost[p] + math.hypot(x[i] - x[p], y[i] - y[p])   # bitwise, rrt_04:1379-1384
+    # acyclic: every node reaches the root
+    depth = np.zeros(len(x), dtype=np.int64)
+    for i in range(1, len(x)):
+        j, d = i, 0
+        while j != 0:
+            j = parent[j]
+            d += 1
+            assert d <= len(x)
+        depth[i] = d
+
+
+def test_host_classes_drop_in(gpu):
+    """The reference's driver usage (rrt_04:1532-1580) against the mirror classes."""
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt04_drv_mt_s1234.npz")
+    kw = util.kwargs_from_golden(g)
+    random.seed(1234)
+    rrt = rrt_amd.RRTStar(start=kw["start"], goal=kw["goal"], obstacle_list=kw["obstacles"], rand_area=kw["rand_area"],
+                          expand_dis=kw["expand_dis"], path_resolution=kw["path_resolution"],
+                          goal_sample_rate=kw["goal_sample_rate"], max_iter=kw["max_iter"], play_area=kw["play_area"],
+                          robot_radius=kw["robot_radius"], sobol_sampler=False, connect_circle_dist=50.0,
+                          search_until_max_iter=True)
+    path = rrt.planning(animation=False)
+    assert len(rrt.node_list) == 150 and len(path) == 24
+    assert rrt_amd.get_path_length(path) == 21.309028648444052
+    assert path[1] == [5.780590352994788, 10.488215966400231]
+    assert random.getstate()[1][624] == int(g["rng_pos_after"])           # global stream advanced as the reference would
+    nd = rrt.node_list[1]
+    assert nd.parent is rrt.node_list[int(g["parent"][1])] and len(nd.path_x) >= 2
+    g1 = util.load_golden(util.GOLDEN + "/rrt01_drv_s42.npz")
+    random.seed(42)
+    r1 = rrt_amd.RRT(start=kw["start"], goal=kw["goal"], obstacle_list=kw["obstacles"], rand_area=kw["rand_area"],
+                     expand_dis=1.0, path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=None,
+                     robot_radius=0.6)
+    p1 = r1.planning(animation=False)
+    assert len(r1.node_list) == 170 and len(p1) == 28 and np.array_equal(np.array(p1), g1["path"])
