@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native batched RRT* planner.
+
+Metric (BASELINE.json): collision-checked edge expansions per second (+ final path cost) while growing
+100k-node RRT* trees (config C2 of SURVEY.md 8d: rrt_04 semantics, 50 circle obstacles on a 100x100 map,
+max_iter 105 000 => ~100k nodes), many independent instances per GPU.
+
+One "step" = one full planning pass of the hot path over one batch: `--instances` independent trees per
+GPU (seeds rank*B+1 ...), each grown for `--max-iter` iterations by the HIP kernels through the C ABI
+(librrtx.so).  Inputs (obstacles, RNG states) are resident in HBM before the timed region.  N GPUs = N
+processes (torch.distributed / RCCL), instances sharded with no data-path collective; the only collective
+is the final all_gather of the 16-byte per-instance result records.  `value` = edge expansions of all ranks
+per step / max-over-ranks step time.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (SURVEY.md 8d:
+sum over iterations of 16*n per scan + 48*k + 24*M + 28) / HIP-event time of the planner kernel launches.
+`cpu_baseline` = the CPU oracle (oracle/rrt_oracle.c, "port") on one host core on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("RRTX_BENCH_INSTANCES", "1024")),
+                    help="planning instances per GPU (weak scaling)")
+    ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
+    ap.add_argument("--obstacles", type=int, default=50)
+    ap.add_argument("--cpu-iters", type=int, default=30000, help="iterations of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warmup-max-iter", type=int, default=0,
+                    help="iterations of a warm-up step (0 = same as a timed step)")
+    a = ap.parse_args()
+
+    import numpy as np
+    import util
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    torch = None
+    if a.gpus > 1 or world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ngpu = max(world, 1)
+    device = local_rank
+
+    import rrt_amd
+    A = rrt_amd._abi
+    kw = util.c2_kwargs(a.max_iter, m=a.obstacles)
+    B = a.instances
+    seeds = [rank * B + i + 1 for i in range(B)]
+
+    def make_handle(max_iter):
+        h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
+                     kw["goal_sample_rate"], max_iter, play_area=None, robot_radius=kw["robot_radius"],
+                     sampler=A.SAMPLER_MT, connect_circle_dist=kw["connect_circle_dist"], search_until_max_iter=True,
+                     n_instances=B, device=device)
+        h.set_obstacles(kw["obstacles"])
+        h.seed_instances(seeds)
+        return h
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    h = make_handle(a.max_iter)
+    hw = h
+    if a.warmup_max_iter and a.warmup_max_iter != a.max_iter:
+        hw = make_handle(a.warmup_max_iter)
+    for _ in range(a.warmup):
+        hw.plan()
+    if hw is not h:
+        hw.close()
+
+    sync_all()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    alg_bytes = 0
+    edges_u = edges_r = iters = launches = 0
+    for _ in range(a.steps):
+        h.plan()                      # blocking: returns after the last kernel of the batch has finished
+        s = h.get_stats()
+        kernel_ms += s["kernel_ms"]
+        alg_bytes += s["algorithmic_bytes"]
+        edges_u += s["edges_unique"]
+        edges_r += s["edges_ref"]
+        iters += s["iterations"]
+        launches += s["launches"]
+    sync_all()
+    dt = time.perf_counter() - t0
+    pc, nn, st = h.get_results()
+    stats = h.get_stats()
+
+    # ---- cross-rank: max time, summed work, RCCL gather of the result table
+    tot_edges_u, tot_edges_r, tmax = edges_u, edges_r, dt
+    all_pc, all_nn = pc, nn
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+        w = torch.tensor([edges_u, edges_r], dtype=torch.int64, device="cuda")
+        dist.all_reduce(w, op=dist.ReduceOp.SUM)
+        tot_edges_u, tot_edges_r = int(w[0].item()), int(w[1].item())
+        rec = torch.from_numpy(np.stack([pc, nn.astype(np.float64)], axis=1)).cuda()   # per-instance result records
+        out = [torch.empty_like(rec) for _ in range(world)]
+        dist.all_gather(out, rec)                                                       # the path-cost gather (RCCL)
+        allr = torch.cat(out).cpu().numpy()
+        all_pc, all_nn = allr[:, 0], allr[:, 1].astype(np.int64)
+
+    if rank == 0:
+        finite = np.isfinite(all_pc)
+        value = tot_edges_u / tmax
+        achieved = (alg_bytes / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "RRT* collision-checked edge expansions/sec (unique edges evaluated on device), "
+                      "%d-iteration trees" % a.max_iter,
+            "value": value, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * tmax / max(a.steps, 1), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "C2: rrt_04 RRT*, %d circle obstacles (map_seed 7) on 100x100, expand_dis 2.0, "
+                                   "path_resolution 0.25, max_iter %d, %d instances/GPU (seeds 1..), MT sampler"
+                                   % (a.obstacles, a.max_iter, B),
+                       "instances_per_gpu": B, "max_iter": a.max_iter, "parallelism": "instances x%d" % ngpu},
+            "edge_expansions_reference_equivalent_per_s": tot_edges_r / tmax,
+            "mean_nodes_per_tree": float(np.mean(all_nn)),
+            "final_path_cost_mean": float(np.mean(all_pc[finite])) if finite.any() else None,
+            "final_path_cost_min": float(np.min(all_pc[finite])) if finite.any() else None,
+            "paths_found": int(finite.sum()), "instances_total": int(len(all_pc)),
+            "iterations_per_s": iters * ngpu / tmax,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "rppk::rrt_plan_kernel", "launches": launches,
+                         "algorithmic_bytes_per_step": alg_bytes / max(a.steps, 1),
+                         "kernel_ms_per_step": kernel_ms / max(a.steps, 1)},
+        }
+        if not a.no_cpu_baseline:
+            import oracle
+            kc = util.c2_kwargs(a.cpu_iters, m=a.obstacles)
+            tc = time.perf_counter()
+            r = oracle.plan(seed=1, exact_pow=False, **kc)
+            tc = time.perf_counter() - tc
+            line["cpu_baseline"] = {"value": r["stats"]["edges_unique"] / tc, "unit": "edge expansions/s", "cores": 1,
+                                    "kind": "port",
+                                    "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference), 1 instance, "
+                                              "seed 1, %d iterations (%d nodes) of the same C2 workload, %.1f s; "
+                                              "reference-equivalent rate %.0f/s"
+                                              % (a.cpu_iters, len(r["x"]), tc, r["stats"]["edges_ref"] / tc)}
+        print(json.dumps(line), flush=True)
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
