@@ -119,6 +119,11 @@ int rrtx_get_stats(rrtx_handle* h, rrtx_stats* st);
 int rrtx_enable_trace(rrtx_handle* h, int32_t instance);
 int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* nearest, int32_t* n_near,
                    int32_t cap, int32_t* n_out);
+/* diagnostic builds only (-DRRTX_PHASE_TIMERS): shader-clock cycles per kernel phase summed over instances
+ * (0 sample, 1 nearest scan, 2 steer, 3 extension collision, 4 near scan, 5 exact re-check + de-dup,
+ *  6 choose_parent edges, 7 choose_parent costs, 8 rewire edges, 9 rewire resolve + propagate + append,
+ *  11 bookkeeping, 12 goal search, 15 loop overhead); all zero in the shipped build. */
+int rrtx_get_phase_cycles(rrtx_handle* h, int64_t* out16);
 const char* rrtx_last_error(rrtx_handle* h);
 void rrtx_destroy(rrtx_handle* h);
 

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrtx.so")
+LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
 RRTX_ABI_VERSION = 1
 ALGO_RRT, ALGO_RRT_STAR = 0, 1
@@ -22,7 +22,7 @@ ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP
 EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_stats",
-           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math"]
+           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math"]
 
 
 class Params(C.Structure):
@@ -79,6 +79,7 @@ def load():
     L.rrtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rrtx_enable_trace.argtypes = [vp, i32]
     L.rrtx_get_trace.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
+    L.rrtx_get_phase_cycles.argtypes = [vp, vp]
     L.rrtx_last_error.argtypes = [vp]
     L.rrtx_last_error.restype = C.c_char_p
     L.rrtx_destroy.argtypes = [vp]
@@ -217,6 +218,11 @@ class Handle:
         s = Stats()
         self._chk(self.L.rrtx_get_stats(self._h, C.byref(s)), "rrtx_get_stats")
         return {k: getattr(s, k) for k, _ in Stats._fields_ if k != "reserved"}
+
+    def get_phase_cycles(self):
+        out = np.zeros(16, dtype=np.int64)
+        self._chk(self.L.rrtx_get_phase_cycles(self._h, out.ctypes.data), "rrtx_get_phase_cycles")
+        return out
 
     def get_trace(self):
         n = C.c_int32()

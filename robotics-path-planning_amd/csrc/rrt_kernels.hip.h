@@ -56,7 +56,18 @@ struct Inst {  // persistent per-instance state (global memory)
   int32_t n, it, status, goal_node, path_n, pad_;
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
       exact_rescans;
+  int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
 };
+
+#ifdef RRTX_PHASE_TIMERS
+#define PH_DECL int64_t ph_[16] = {0}; int64_t pt0_ = (int64_t)__builtin_amdgcn_s_memtime();
+#define PH(k) do { if (threadIdx.x == 0) { int64_t t_ = (int64_t)__builtin_amdgcn_s_memtime(); ph_[k] += t_ - pt0_; pt0_ = t_; } } while (0)
+#define PH_STORE(I) do { for (int k_ = 0; k_ < 16; k_++) (I)->phase[k_] += ph_[k_]; } while (0)
+#else
+#define PH_DECL
+#define PH(k) do { } while (0)
+#define PH_STORE(I) do { } while (0)
+#endif
 
 struct Ctx {
   Inst* inst;
@@ -483,7 +494,7 @@ __device__ __forceinline__ int best_goal_node(const Ctx& c, Inst* I, const doubl
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
+__global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
   __shared__ Sh sh;
   const int inst = blockIdx.x;
   const int tid = threadIdx.x;
@@ -517,9 +528,11 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
   rpp::Sobol sob = I->sobol;
   int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_pr = 0, s_sn = 0, s_ab = 0, s_ex = 0;
   int done = 0;
+  PH_DECL
 
   for (int step = 0; step < iters && it < c.max_iter && !done; step++, it++) {
     s_iter++;
+    PH(15);
     // ---------------- sample (lane 0) rrt_04:1132-1153
     if (tid == 0) {
       double rx, ry;
@@ -542,6 +555,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
     }
     __syncthreads();
     const double rx = sh.rx, ry = sh.ry;
+    PH(0);
 
     // ---------------- nearest :1197-1202
     int ni;
@@ -566,6 +580,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
       double gb2, gs2;
       block_argmin(best, bidx, second, sh, gb2, ni, gs2);
     }
+    PH(1);
 
     // ---------------- steer + collision of the extension :1051-1059
     if (tid == 0) {
@@ -577,6 +592,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
       sh.flag = rpp::in_play_area(c.has_play, c.play_area, sh.edge[0].ex, sh.edge[0].ey) ? 1 : 0;
     }
     __syncthreads();
+    PH(2);
     const double nx = sh.nx, ny = sh.ny;
     const int inplay = sh.flag;
     if (inplay) {
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
     __syncthreads();
     const int accepted = inplay && !sh.ecoll[0];
     int nnear = -1;
+    PH(3);
 
     if (accepted && c.algo == 0) {
       // ---- rrt_01:85-96
@@ -634,7 +651,9 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
       const double r2 = c.r2tab[n + 1];
       const int kraw = scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
       s_sn += n;
+      PH(4);
       exact_dedup(x, y, nx, ny, r2, 0, hits, kraw, sh);
+      PH(5);
       const int nu = sh.nu;
       const int nvalid = sh.nvalid;
       nnear = nu;
@@ -648,6 +667,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
         s_eu += nu;
         s_er += nvalid;
         eval_edges(c, x, y, nu, 0, nx, ny, sh);
+        PH(6);
         for (int e = tid; e < nu; e += TPB) {
           const int u = sh.uidx[e];
           sh.uaux[e] = sh.usafe[e] ? cost[u] + rpp::py_hypot(nx - x[u], ny - y[u]) : rpp::dinf();  // :1269
@@ -655,6 +675,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
         __syncthreads();
         first_min(nu, sh, min_cost, sel);
         have = min_cost < rpp::dinf();
+        PH(7);
       }
       if (have) {
         // new_node = steer(node_list[min_ind], new_node); cost = min_cost  (:1279-1280)
@@ -670,6 +691,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
           sh.uaux[e] = wcost + rpp::py_hypot(x[u] - wx, y[u] - wy);  // edge_node.cost :1362
         }
         __syncthreads();
+        PH(8);
         if (tid == 0) {
           const int newidx = n;
           first_child[newidx] = -1;
@@ -696,6 +718,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
           sh.sel = npr;
         }
         __syncthreads();
+        PH(9);
         s_rw += sh.flag;
         s_pr += sh.sel;
         n++;
@@ -721,6 +744,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
     }
 
     // ---------------- early exit :1072-1076
+    PH(11);
     if (c.algo == 1 && !c.until_max) {
       s_sn += n;
       s_ab += 16 * (int64_t)n;
@@ -732,6 +756,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
       __syncthreads();
     }
     if (sh.overflow) done = 1;
+    PH(12);
   }
 
   // ---------------- after the loop :1078-1084
@@ -766,6 +791,7 @@ __global__ __launch_bounds__(TPB) void rrt_plan_kernel(Ctx c, int iters) {
     I->scan_nodes += s_sn;
     I->alg_bytes += s_ab;
     I->exact_rescans += s_ex;
+    PH_STORE(I);
     c.results[inst].n_nodes = n;
     c.results[inst].status = I->status;
   }
@@ -802,6 +828,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   I->sobol.lastq[0] = I->sobol.lastq[1] = 0;
   I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
   I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = 0;
+  for (int k = 0; k < 16; k++) I->phase[k] = 0;
   c.results[inst].path_cost = 0.0;
   c.results[inst].n_nodes = 1;
   c.results[inst].status = 0;

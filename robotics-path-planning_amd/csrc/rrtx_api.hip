@@ -48,6 +48,7 @@ struct rrtx_handle {
   std::vector<double> obst;
   int trace_inst = -1;
   rrtx_stats stats;
+  int64_t phase[16] = {0};
   std::string err;
   std::vector<void*> allocs;
   int chunk_iters = 1024;
@@ -310,6 +311,7 @@ int rrtx_plan(rrtx_handle* h) {
   HIPCHK(h, hipMemcpy(back.data(), c.inst, sizeof(Inst) * B, hipMemcpyDeviceToHost));
   rrtx_stats& s = h->stats;
   memset(&s, 0, sizeof(s));
+  memset(h->phase, 0, sizeof(h->phase));
   bool overflow = false;
   for (int i = 0; i < B; i++) {
     const Inst& I = back[i];
@@ -325,6 +327,7 @@ int rrtx_plan(rrtx_handle* h) {
     s.exact_rescans += I.exact_rescans;
     s.total_nodes += I.n;
     if (I.status & RRTX_ST_OVERFLOW) overflow = true;
+    for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];
   }
   s.launches = launches;
   s.kernel_ms = kms;
@@ -427,6 +430,12 @@ int rrtx_get_sobol_index(rrtx_handle* h, int32_t instance, int64_t* index) {
 int rrtx_get_stats(rrtx_handle* h, rrtx_stats* st) {
   if (!h || !st) return RRTX_E_INVALID;
   *st = h->stats;
+  return RRTX_OK;
+}
+
+int rrtx_get_phase_cycles(rrtx_handle* h, int64_t* out16) {
+  if (!h || !out16) return RRTX_E_INVALID;
+  memcpy(out16, h->phase, sizeof(h->phase));
   return RRTX_OK;
 }
 

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-phase cycle shares of the planner kernel from the -DRRTX_PHASE_TIMERS build.
+Usage: RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so python tools/phase_profile.py [instances] [max_iter]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import util  # noqa: E402
+import rrt_amd  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+it = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+A = rrt_amd._abi
+kw = util.c2_kwargs(it)
+h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
+             kw["goal_sample_rate"], it, robot_radius=0.0, connect_circle_dist=50.0, search_until_max_iter=True,
+             n_instances=B)
+h.set_obstacles(kw["obstacles"])
+h.seed_instances(list(range(1, B + 1)))
+h.plan()
+s = h.get_stats()
+ph = h.get_phase_cycles()
+names = {0: "sample", 1: "nearest scan", 2: "ext steer", 3: "ext collision", 4: "near scan", 5: "exact+dedup",
+         6: "choose edges", 7: "choose cost/min", 8: "rewire edges", 9: "rewire seq+propagate+append", 11: "bookkeeping",
+         12: "goal", 15: "loop"}
+tot = float(ph.sum())
+print("instances", B, "max_iter", it, "kernel_ms", s["kernel_ms"], "alg GB/s", s["algorithmic_bytes"] / 1e6 / s["kernel_ms"])
+for k in sorted(names):
+    print("  %-30s %6.2f%%  %.1f cycles/iter/inst" % (names[k], 100.0 * ph[k] / tot if tot else 0, ph[k] / max(s["iterations"], 1)))
+print("  total cycles/iter/inst %.1f" % (tot / max(s["iterations"], 1)))
+print({k: s[k] for k in ("iterations", "edges_unique", "near_unique", "rewires", "propagated", "exact_rescans")})
