@@ -92,13 +92,14 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     kernel_ms = 0.0
-    alg_bytes = 0
+    alg_bytes = alg_bytes2 = 0
     edges_u = edges_r = iters = launches = 0
     for _ in range(a.steps):
         h.plan()                      # blocking: returns after the last kernel of the batch has finished
         s = h.get_stats()
         kernel_ms += s["kernel_ms"]
         alg_bytes += s["algorithmic_bytes"]
+        alg_bytes2 += s["algorithmic_bytes_two_scan"]
         edges_u += s["edges_unique"]
         edges_r += s["edges_ref"]
         iters += s["iterations"]
@@ -148,6 +149,7 @@ def main():
                          "frac": achieved / 8000.0, "traffic": None,
                          "kernel": "rppk::rrt_plan_kernel", "launches": launches,
                          "algorithmic_bytes_per_step": alg_bytes / max(a.steps, 1),
+                         "survey_8d_two_scan_formula_GBps": (alg_bytes2 / 1e9) / (kernel_ms / 1e3) if kernel_ms else 0.0,
                          "kernel_ms_per_step": kernel_ms / max(a.steps, 1)},
         }
         if not a.no_cpu_baseline:

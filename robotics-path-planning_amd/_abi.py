@@ -42,7 +42,8 @@ class Stats(C.Structure):
                 ("near_hits", C.c_int64), ("near_unique", C.c_int64), ("rewires", C.c_int64),
                 ("propagated", C.c_int64), ("scan_nodes", C.c_int64), ("algorithmic_bytes", C.c_int64),
                 ("exact_rescans", C.c_int64), ("total_nodes", C.c_int64), ("launches", C.c_int64),
-                ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("reserved", C.c_int64 * 8)]
+                ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("algorithmic_bytes_two_scan", C.c_int64),
+                ("reserved", C.c_int64 * 7)]
 
 
 class RrtxError(RuntimeError):

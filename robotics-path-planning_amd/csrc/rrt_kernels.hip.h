@@ -55,7 +55,7 @@ struct Inst {  // persistent per-instance state (global memory)
   double start[2], goal[2];
   int32_t n, it, status, goal_node, path_n, pad_;
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
-      exact_rescans;
+      exact_rescans, alg_bytes2;
   int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
 };
 
@@ -245,6 +245,76 @@ __device__ __forceinline__ int scan_hits(const double* __restrict__ x, const dou
     sh.wave_start[w] = ws;
   }
   __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
+  return total;
+}
+
+// ---------------------------------------------------------------------------
+// Fused pass: ONE stream over x[0..n), y[0..n) serves two queries -- the near-ball
+// threshold scan about (qx,qy) of THIS iteration (rrt_04:1335-1337) and the
+// nearest-node argmin about (sx,sy), the sample of the NEXT iteration
+// (rrt_04:1198-1200).  The next sample does not depend on the tree (the RNG stream
+// is consumed in the same order), and the node appended at the end of this
+// iteration is folded into the argmin afterwards, so every node is read once per
+// iteration instead of twice.
+__device__ __forceinline__ int scan_fused(const double* __restrict__ x, const double* __restrict__ y, int n, double qx,
+                                          double qy, double thr, double sx, double sy, int32_t* __restrict__ hits,
+                                          Sh& sh, int& ni, double& gbest, double& gsecond) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
+  const int ws = w * per;
+  const int we = ws + per;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int cnt = 0;
+  double best = rpp::dinf(), second = rpp::dinf();
+  int bidx = 0x7fffffff;
+  for (int base = ws; base < we && base < n; base += WAVE_STRIDE) {
+    double2 xv[UNROLL], yv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 128 + lane * 2;
+      xv[u] = *reinterpret_cast<const double2*>(x + i0);
+      yv[u] = *reinterpret_cast<const double2*>(y + i0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 128 + lane * 2;
+      {
+        double dx = xv[u].x - sx, dy = yv[u].x - sy;
+        double d = dx * dx + dy * dy;
+        bool lt = d < best;
+        second = lt ? best : (d < second ? d : second);
+        bidx = lt ? i0 : bidx;
+        best = lt ? d : best;
+      }
+      {
+        double dx = xv[u].y - sx, dy = yv[u].y - sy;
+        double d = dx * dx + dy * dy;
+        bool lt = d < best;
+        second = lt ? best : (d < second ? d : second);
+        bidx = lt ? i0 + 1 : bidx;
+        best = lt ? d : best;
+      }
+      double dx0 = xv[u].x - qx, dy0 = yv[u].x - qy;
+      double dx1 = xv[u].y - qx, dy1 = yv[u].y - qy;
+      bool h0 = (dx0 * dx0 + dy0 * dy0) <= thr;
+      bool h1 = (dx1 * dx1 + dy1 * dy1) <= thr;
+      uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+      if ((m0 | m1) != 0ull) {
+        int pos = cnt + __popcll(m0 & lt_mask) + __popcll(m1 & lt_mask);
+        if (h0) hits[ws + pos] = i0;
+        if (h1) hits[ws + pos + (h0 ? 1 : 0)] = i0 + 1;
+        cnt += __popcll(m0) + __popcll(m1);
+      }
+    }
+  }
+  if (lane == 0) {
+    sh.wave_cnt[w] = cnt;
+    sh.wave_start[w] = ws;
+  }
+  block_argmin(best, bidx, second, sh, gbest, ni, gsecond);  // contains the barriers that publish wave_cnt
   int total = 0;
 #pragma unroll
   for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
@@ -493,6 +563,27 @@ __device__ __forceinline__ int best_goal_node(const Ctx& c, Inst* I, const doubl
   return sh.uidx[sel];
 }
 
+// get_random_node / get_random_node_sobol (rrt_04:1132-1153), lane 0; result in sh.rx, sh.ry
+__device__ __forceinline__ void draw_sample(const Ctx& c, Sh& sh, rpp::Sobol& sob, double gx, double gy) {
+  double rx, ry;
+  if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {
+    if (c.sampler == 1 && c.algo == 1) {
+      double q[2];
+      rpp::sobol_next(&sob, q);
+      rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);
+      ry = c.rand_min + q[1] * (c.rand_max - c.rand_min);
+    } else {
+      rx = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
+      ry = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
+    }
+  } else {
+    rx = gx;
+    ry = gy;
+  }
+  sh.rx = rx;
+  sh.ry = ry;
+}
+
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
   __shared__ Sh sh;
@@ -528,41 +619,38 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
   rpp::Sobol sob = I->sobol;
   int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_pr = 0, s_sn = 0, s_ab = 0, s_ex = 0;
   int done = 0;
+  int have_sample = 0, have_nearest = 0, pf_ni = 0;   // block-uniform prefetch state (never carried across launches)
+  double pf_best = 0.0, pf_second = 0.0;
+  int64_t s_ab2 = 0;
   PH_DECL
 
   for (int step = 0; step < iters && it < c.max_iter && !done; step++, it++) {
     s_iter++;
     PH(15);
-    // ---------------- sample (lane 0) rrt_04:1132-1153
-    if (tid == 0) {
-      double rx, ry;
-      if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {
-        if (c.sampler == 1 && c.algo == 1) {
-          double q[2];
-          rpp::sobol_next(&sob, q);
-          rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);
-          ry = c.rand_min + q[1] * (c.rand_max - c.rand_min);
-        } else {
-          rx = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
-          ry = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
-        }
-      } else {
-        rx = gx;
-        ry = gy;
-      }
-      sh.rx = rx;
-      sh.ry = ry;
+    // ---------------- sample (lane 0) rrt_04:1132-1153 (already drawn when the previous iteration prefetched it)
+    if (!have_sample) {
+      if (tid == 0) draw_sample(c, sh, sob, gx, gy);
+      __syncthreads();
     }
-    __syncthreads();
     const double rx = sh.rx, ry = sh.ry;
+    have_sample = 0;
     PH(0);
 
-    // ---------------- nearest :1197-1202
+    // ---------------- nearest :1197-1202 (already known when the previous iteration's fused pass covered it)
     int ni;
     double gbest, gsecond;
-    scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
-    s_sn += n;
-    s_ab += 16 * (int64_t)n + 24 * (int64_t)c.m;
+    s_ab2 += 16 * (int64_t)n + 24 * (int64_t)c.m;
+    s_ab += 24 * (int64_t)c.m;
+    if (have_nearest) {
+      ni = pf_ni;
+      gbest = pf_best;
+      gsecond = pf_second;
+      have_nearest = 0;
+    } else {
+      scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
+      s_sn += n;
+      s_ab += 16 * (int64_t)n;
+    }
     if (gbest != 0.0 && gsecond <= gbest * (1.0 + FILTER_EPS)) {
       // two candidates inside the filter margin: re-decide with the exact ** 2
       s_ex++;
@@ -617,6 +705,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
       }
       n++;
       s_ab += 28;
+      s_ab2 += 28;
       __syncthreads();
     }
     if (c.algo == 0) {
@@ -649,8 +738,24 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
     if (accepted && c.algo == 1) {
       // ---------------- find_near_nodes :1314-1338
       const double r2 = c.r2tab[n + 1];
-      const int kraw = scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
+      // Prefetch: draw the NEXT iteration's sample now (same RNG order: nothing below consumes the stream) and
+      // let this pass also find its nearest node.  Only when the loop is known to run on (search_until_max_iter,
+      // not the last iteration of this launch / of the plan), so the RNG state handed back is the reference's.
+      const int do_pf = c.until_max && (step + 1 < iters) && (it + 1 < c.max_iter);
+      const int n_scan = n;
+      int kraw;
+      if (do_pf) {
+        if (tid == 0) draw_sample(c, sh, sob, gx, gy);
+        __syncthreads();
+        kraw = scan_fused(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), sh.rx, sh.ry, hits, sh, pf_ni, pf_best, pf_second);
+        have_sample = 1;
+        have_nearest = 1;
+      } else {
+        kraw = scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
+      }
       s_sn += n;
+      s_ab2 += 16 * (int64_t)n;
+      s_ab += 16 * (int64_t)n;
       PH(4);
       exact_dedup(x, y, nx, ny, r2, 0, hits, kraw, sh);
       PH(5);
@@ -659,7 +764,8 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
       nnear = nu;
       s_nh += nvalid;
       s_nu += nu;
-      s_ab += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
+      s_ab += 48 * (int64_t)nu + 28;
+      s_ab2 += 48 * (int64_t)nu + 28;
       // ---------------- choose_parent :1242-1282
       int have = 0, sel = -1;
       double min_cost = rpp::dinf();
@@ -695,12 +801,13 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
         if (tid == 0) {
           const int newidx = n;
           first_child[newidx] = -1;
-          int nrw = 0, npr = 0;
+          int nrw = 0, npr = 0, moved = 0;
           for (int e = 0; e < nu; e++) {  // list order; later entries see earlier updates
             const int u = sh.uidx[e];
             const double ec = sh.uaux[e];
             if (sh.usafe[e] && cost[u] > ec) {  // :1366-1368 strict
               unlink_child(parent, first_child, next_sib, prev_sib, u);
+              if (x[u] != sh.uex[e] || y[u] != sh.uey[e]) moved = 1;  // steer did not snap back onto the node
               x[u] = sh.uex[e];  // node_list[i] = edge_node :1372 (same xy whenever steer snapped)
               y[u] = sh.uey[e];
               cost[u] = ec;
@@ -716,11 +823,13 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
           link_child(parent, first_child, next_sib, prev_sib, newidx, min_ind);
           sh.flag = nrw;
           sh.sel = npr;
+          sh.nvalid = moved;
         }
         __syncthreads();
         PH(9);
         s_rw += sh.flag;
         s_pr += sh.sel;
+        if (sh.nvalid) have_nearest = 0;  // a rewired node changed coordinates: the prefetched argmin is stale
         n++;
       } else {
         // choose_parent returned None: append the extension as it is (:1066-1067)
@@ -736,6 +845,20 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
       }
     }
 
+    if (have_nearest) {
+      // fold the node appended by this iteration (index n-1, not covered by the fused pass) into the argmin;
+      // it has the highest index, so it wins strict improvements only (first-minimum rule, rrt_04:1200)
+      const int last = n - 1;
+      const double dxl = x[last] - sh.rx, dyl = y[last] - sh.ry;
+      const double dl = dxl * dxl + dyl * dyl;
+      if (dl < pf_best) {
+        pf_second = pf_best;
+        pf_best = dl;
+        pf_ni = last;
+      } else if (dl < pf_second) {
+        pf_second = dl;
+      }
+    }
     if (inst == c.trace_inst && tid == 0) {
       c.tr_rx[it] = rx;
       c.tr_ry[it] = ry;
@@ -748,6 +871,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
     if (c.algo == 1 && !c.until_max) {
       s_sn += n;
       s_ab += 16 * (int64_t)n;
+      s_ab2 += 16 * (int64_t)n;
       const int gi = best_goal_node(c, I, x, y, cost, hits, n, sh, s_eu, s_er);
       if (gi >= 0) {
         if (tid == 0) write_path(c, I, x, y, parent, inst, gi);
@@ -764,6 +888,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
     if (c.algo == 1) {
       s_sn += n;
       s_ab += 16 * (int64_t)n;
+      s_ab2 += 16 * (int64_t)n;
       const int gi = best_goal_node(c, I, x, y, cost, hits, n, sh, s_eu, s_er);
       if (gi >= 0 && tid == 0) write_path(c, I, x, y, parent, inst, gi);
       __syncthreads();
@@ -791,6 +916,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
     I->scan_nodes += s_sn;
     I->alg_bytes += s_ab;
     I->exact_rescans += s_ex;
+    I->alg_bytes2 += s_ab2;
     PH_STORE(I);
     c.results[inst].n_nodes = n;
     c.results[inst].status = I->status;
@@ -827,7 +953,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   I->sobol.index = 0;
   I->sobol.lastq[0] = I->sobol.lastq[1] = 0;
   I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
-  I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = 0;
+  I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = I->alg_bytes2 = 0;
   for (int k = 0; k < 16; k++) I->phase[k] = 0;
   c.results[inst].path_cost = 0.0;
   c.results[inst].n_nodes = 1;

@@ -325,6 +325,7 @@ int rrtx_plan(rrtx_handle* h) {
     s.scan_nodes += I.scan_nodes;
     s.algorithmic_bytes += I.alg_bytes;
     s.exact_rescans += I.exact_rescans;
+    s.algorithmic_bytes_two_scan += I.alg_bytes2;
     s.total_nodes += I.n;
     if (I.status & RRTX_ST_OVERFLOW) overflow = true;
     for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];
