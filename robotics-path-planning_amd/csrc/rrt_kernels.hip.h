@@ -40,7 +40,9 @@ constexpr int UNROLL = 4;
 constexpr int WAVE_STRIDE = 128 * UNROLL;  // nodes one wave consumes per loop trip
 constexpr int MAX_OBS = 256;
 constexpr int NU_MAX = 512;   // distinct near candidates kept in LDS
-constexpr int EB = 64;        // edges steered per pass
+constexpr int EB = 64;        // edges steered per pass (single-direction form)
+constexpr int EBD = 32;       // candidates per pass of the two-direction form (2*EBD edge slots)
+constexpr int FCAP = TPB;     // BFS frontier capacity in LDS (2 buffers inside Sh::cval)
 constexpr double FILTER_EPS = 7.105427357601002e-15;  // 2^-47
 
 struct Result {  // 16 B record gathered across GPUs
@@ -105,6 +107,7 @@ struct Sh {
   int32_t wave_start[NW];
   double rx, ry, nx, ny, ncost, wx, wy, wcost;
   int32_t ni, flag, nu, nvalid, sel, overflow;
+  int32_t fa, fb, fover, fcount;   // BFS frontier sizes / overflow / visited count (propagate_bfs)
 };
 
 __device__ __forceinline__ int roundup_i(int a, int b) { return (a + b - 1) / b * b; }
@@ -443,12 +446,156 @@ __device__ __forceinline__ void eval_edges(const Ctx& c, const double* __restric
     __syncthreads();
     if (tid < nb) {
       const rpp::Edge& e = sh.edge[tid];
-      sh.uex[base + tid] = e.ex;
-      sh.uey[base + tid] = e.ey;
-      sh.usafe[base + tid] = (!sh.ecoll[tid]) && rpp::in_play_area(c.has_play, c.play_area, e.ex, e.ey);
+      const int s = (!sh.ecoll[tid]) && rpp::in_play_area(c.has_play, c.play_area, e.ex, e.ey);
+      if (kind == 0) {
+        sh.uex[base + tid] = e.ex;
+        sh.uey[base + tid] = e.ey;
+        sh.usafe[base + tid] = s;
+      } else {  // backward edges recomputed from the true new-node position: refresh bits 1,2 only
+        const int s2 = (e.ex == e.tx) && (e.ey == e.ty);
+        sh.usafe[base + tid] = (sh.usafe[base + tid] & 1) | (s << 1) | (s2 << 2);
+      }
     }
     __syncthreads();
   }
+}
+
+// block-wide minimum of an int (block-uniform result)
+__device__ __forceinline__ int block_min_int(int v, Sh& sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    int ov = __shfl_xor(v, o);
+    v = ov < v ? ov : v;
+  }
+  if (lane == 0) sh.red_idx[w] = v;
+  __syncthreads();
+  int r = sh.red_idx[0];
+#pragma unroll
+  for (int k = 1; k < NW; k++) r = sh.red_idx[k] < r ? sh.red_idx[k] : r;
+  __syncthreads();
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// Both directions of every candidate edge in one go (choose_parent's steer(node -> new), rrt_04:1265, and
+// rewire's steer(new -> node), :1359, speculating that the new node keeps the extension's coordinates, which
+// it does whenever the winning edge snaps onto it).  The four waves split the serial libm chain: wave w handles
+// direction w>>1 and evaluates cos (w even) or sin (w odd) of the edge angle; lane = candidate.
+// Out per candidate e: uex/uey = end of the forward edge, uaux = hypot(new - node) (= hypot(node - new)),
+// usafe bit0 = forward edge safe, bit1 = backward edge safe, bit2 = backward edge ends exactly on the node.
+__device__ __forceinline__ void eval_edges_dual(const Ctx& c, const double* __restrict__ x, const double* __restrict__ y,
+                                                int nu, double nx, double ny, Sh& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int kind = w >> 1, trig = w & 1;
+  for (int base = 0; base < nu; base += EBD) {
+    const int nb = (nu - base) < EBD ? (nu - base) : EBD;
+    const bool act = lane < nb;
+    rpp::Edge& E = sh.edge[kind * EBD + (lane & (EBD - 1))];
+    if (act) {
+      const int u = sh.uidx[base + lane];
+      const double ux = x[u], uy = y[u];
+      const double fx = kind ? nx : ux, fy = kind ? ny : uy, tx = kind ? ux : nx, ty = kind ? uy : ny;
+      const double dx = tx - fx, dy = ty - fy;
+      const double d = rpp::py_hypot(dx, dy);
+      const double theta = rpp_glibc_atan2(dy, dx);
+      if (trig == 0) {
+        E.sx = c.res * rpp_glibc_cos(theta);
+        E.fx = fx; E.fy = fy; E.tx = tx; E.ty = ty;
+        E.n_expand = (int)__builtin_floor(d / c.res);   // extend_length = inf -> d (:1094-1097)
+        if (kind == 0) sh.uaux[base + lane] = d;
+      } else {
+        E.sy = c.res * rpp_glibc_sin(theta);
+      }
+    }
+    __syncthreads();
+    if (act && trig == 0) {
+      double px = E.fx, py = E.fy;
+      const double sx = E.sx, sy = E.sy;
+      for (int i = 0; i < E.n_expand; i++) {
+        px += sx;
+        py += sy;
+      }
+      const int snapped = rpp::py_hypot(E.tx - px, E.ty - py) <= c.res;
+      E.ex = snapped ? E.tx : px;
+      E.ey = snapped ? E.ty : py;
+      E.snapped = snapped;
+      sh.ecoll[kind * EBD + lane] = 0;
+    }
+    __syncthreads();
+    for (int p = tid; p < 2 * nb * c.m; p += TPB) {
+      const int q = p / c.m, k = p - q * c.m;
+      const int kk = q / nb, e = q - kk * nb;
+      const int slot = kk * EBD + e;
+      if (rpp::edge_hits_obstacle(sh.edge[slot], sh.ox[k], sh.oy[k], sh.othr[k])) sh.ecoll[slot] = 1;
+    }
+    __syncthreads();
+    if (tid < nb) {
+      const rpp::Edge& f = sh.edge[tid];
+      const rpp::Edge& b = sh.edge[EBD + tid];
+      sh.uex[base + tid] = f.ex;
+      sh.uey[base + tid] = f.ey;
+      const int s0 = (!sh.ecoll[tid]) && rpp::in_play_area(c.has_play, c.play_area, f.ex, f.ey);
+      const int s1 = (!sh.ecoll[EBD + tid]) && rpp::in_play_area(c.has_play, c.play_area, b.ex, b.ey);
+      const int s2 = (b.ex == b.tx) && (b.ey == b.ty);
+      sh.usafe[base + tid] = s0 | (s1 << 1) | (s2 << 2);
+    }
+    __syncthreads();
+  }
+}
+
+// propagate_cost_to_leaves (rrt_04:1379-1384) as a level-synchronous sweep over the child lists by the whole
+// workgroup (values are order independent).  Frontiers live in LDS (Sh::cval); returns the
+// number of nodes rewritten, or -1 when a level outgrew the LDS frontier (caller falls back to the one-lane walk).
+__device__ __forceinline__ int propagate_bfs(const double* __restrict__ x, const double* __restrict__ y,
+                                             double* __restrict__ cost, const int32_t* __restrict__ first_child,
+                                             const int32_t* __restrict__ next_sib, int root, Sh& sh) {
+  int32_t* A = reinterpret_cast<int32_t*>(sh.cval);
+  int32_t* Bf = A + FCAP;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    A[0] = root;
+    sh.fa = 1;
+    sh.fb = 0;
+    sh.fover = 0;
+    sh.fcount = 0;
+  }
+  __syncthreads();
+  for (;;) {
+    const int na = sh.fa;
+    if (na == 0) break;
+    int cnt = 0;
+    for (int i = tid; i < na; i += TPB) {
+      const int p = A[i];
+      const double cp = cost[p], xp = x[p], yp = y[p];
+      int ch = first_child[p];
+      while (ch >= 0) {
+        const double xc = x[ch], yc = y[ch];
+        const int nxs = next_sib[ch];
+        cost[ch] = cp + rpp::py_hypot(xc - xp, yc - yp);   // calc_new_cost :1375-1377
+        const int slot = atomicAdd(&sh.fb, 1);
+        if (slot < FCAP)
+          Bf[slot] = ch;
+        else
+          sh.fover = 1;
+        ch = nxs;
+        cnt++;
+      }
+    }
+    if (cnt) atomicAdd(&sh.fcount, cnt);
+    __syncthreads();
+    if (sh.fover) return -1;
+    int32_t* t = A;
+    A = Bf;
+    Bf = t;
+    __syncthreads();
+    if (tid == 0) {
+      sh.fa = sh.fb;
+      sh.fb = 0;
+    }
+    __syncthreads();
+  }
+  return sh.fcount;
 }
 
 // first minimum of sh.uaux[0..ne) (list order), block-wide
@@ -766,20 +913,31 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
       s_nu += nu;
       s_ab += 48 * (int64_t)nu + 28;
       s_ab2 += 48 * (int64_t)nu + 28;
-      // ---------------- choose_parent :1242-1282
+      // ---------------- choose_parent :1242-1282 (+ speculative backward edges for rewire)
       int have = 0, sel = -1;
       double min_cost = rpp::dinf();
       if (nu > 0) {
         s_eu += nu;
         s_er += nvalid;
-        eval_edges(c, x, y, nu, 0, nx, ny, sh);
+        eval_edges_dual(c, x, y, nu, nx, ny, sh);
         PH(6);
         for (int e = tid; e < nu; e += TPB) {
           const int u = sh.uidx[e];
-          sh.uaux[e] = sh.usafe[e] ? cost[u] + rpp::py_hypot(nx - x[u], ny - y[u]) : rpp::dinf();  // :1269
+          sh.uval[e] = (sh.usafe[e] & 1) ? cost[u] + sh.uaux[e] : rpp::dinf();  // near.cost + hypot(new - near) :1269
         }
         __syncthreads();
-        first_min(nu, sh, min_cost, sel);
+        {  // first minimum in list order (:1272-1278)
+          double best = rpp::dinf(), second = rpp::dinf(), gs;
+          int bidx = 0x7fffffff;
+          for (int e = tid; e < nu; e += TPB) {
+            const double d = sh.uval[e];
+            if (d < best) {
+              best = d;
+              bidx = e;
+            }
+          }
+          block_argmin(best, bidx, second, sh, min_cost, sel, gs);
+        }
         have = min_cost < rpp::dinf();
         PH(7);
       }
@@ -787,43 +945,75 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
         // new_node = steer(node_list[min_ind], new_node); cost = min_cost  (:1279-1280)
         const double wx = sh.uex[sel], wy = sh.uey[sel], wcost = min_cost;
         const int min_ind = sh.uidx[sel];
+        const int newidx = n;
         __syncthreads();
         // ---------------- rewire (before append) :1340-1373
         s_eu += nu;
         s_er += nvalid;
-        eval_edges(c, x, y, nu, 1, wx, wy, sh);
+        if (wx != nx || wy != ny) {
+          // the winning edge stopped short of the extension point: redo the backward edges from where it ended
+          eval_edges(c, x, y, nu, 1, wx, wy, sh);
+          for (int e = tid; e < nu; e += TPB) {
+            const int u = sh.uidx[e];
+            sh.uaux[e] = rpp::py_hypot(x[u] - wx, y[u] - wy);
+          }
+          __syncthreads();
+        }
         for (int e = tid; e < nu; e += TPB) {
-          const int u = sh.uidx[e];
-          sh.uaux[e] = wcost + rpp::py_hypot(x[u] - wx, y[u] - wy);  // edge_node.cost :1362
+          sh.uval[e] = wcost + sh.uaux[e];   // edge_node.cost = new.cost + hypot(near - new) :1362
+          sh.uex[e] = cost[sh.uidx[e]];       // current cost of the candidate (refreshed after every propagation)
+        }
+        if (tid == 0) {
+          first_child[newidx] = -1;
+          sh.flag = 0;    // rewires
+          sh.sel = 0;     // propagated nodes
+          sh.nvalid = 0;  // a node changed coordinates
         }
         __syncthreads();
         PH(8);
-        if (tid == 0) {
-          const int newidx = n;
-          first_child[newidx] = -1;
-          int nrw = 0, npr = 0, moved = 0;
-          for (int e = 0; e < nu; e++) {  // list order; later entries see earlier updates
-            const int u = sh.uidx[e];
-            const double ec = sh.uaux[e];
-            if (sh.usafe[e] && cost[u] > ec) {  // :1366-1368 strict
-              unlink_child(parent, first_child, next_sib, prev_sib, u);
-              if (x[u] != sh.uex[e] || y[u] != sh.uey[e]) moved = 1;  // steer did not snap back onto the node
-              x[u] = sh.uex[e];  // node_list[i] = edge_node :1372 (same xy whenever steer snapped)
-              y[u] = sh.uey[e];
-              cost[u] = ec;
-              link_child(parent, first_child, next_sib, prev_sib, u, newidx);
-              nrw++;
-              npr += propagate(x, y, cost, first_child, next_sib, stack, u);  // :1373
+        // list order; later entries see costs updated by earlier successes (:1357-1373)
+        for (int e0 = 0; e0 < nu;) {
+          int cand = 0x7fffffff;
+          for (int e = e0 + tid; e < nu; e += TPB) {
+            if ((sh.usafe[e] & 2) && sh.uex[e] > sh.uval[e]) {  // no_collision and improved_cost (strict) :1366-1368
+              cand = e;
+              break;
             }
           }
+          const int es = block_min_int(cand, sh);
+          if (es == 0x7fffffff) break;
+          const int u = sh.uidx[es];
+          if (tid == 0) {
+            unlink_child(parent, first_child, next_sib, prev_sib, u);
+            if (!(sh.usafe[es] & 4)) {
+              // steer(new -> node) did not snap onto the node: node_list[i] = edge_node moves it (:1372)
+              rpp::steer(&sh.edge[0], wx, wy, x[u], y[u], rpp::dinf(), c.res);
+              x[u] = sh.edge[0].ex;
+              y[u] = sh.edge[0].ey;
+              sh.nvalid = 1;
+            }
+            cost[u] = sh.uval[es];
+            link_child(parent, first_child, next_sib, prev_sib, u, newidx);
+            sh.flag++;
+          }
+          __syncthreads();
+          int np = propagate_bfs(x, y, cost, first_child, next_sib, u, sh);   // :1373
+          if (np < 0) {
+            if (tid == 0) sh.fcount = propagate(x, y, cost, first_child, next_sib, stack, u);
+            __syncthreads();
+            np = sh.fcount;
+          }
+          if (tid == 0) sh.sel += np;
+          for (int e = es + 1 + tid; e < nu; e += TPB) sh.uex[e] = cost[sh.uidx[e]];
+          __syncthreads();
+          e0 = es + 1;
+        }
+        if (tid == 0) {
           // append :1065
           x[newidx] = wx;
           y[newidx] = wy;
           cost[newidx] = wcost;
           link_child(parent, first_child, next_sib, prev_sib, newidx, min_ind);
-          sh.flag = nrw;
-          sh.sel = npr;
-          sh.nvalid = moved;
         }
         __syncthreads();
         PH(9);
