@@ -156,6 +156,7 @@ RPP_HD static inline double py_hypot(double a, double b) {
   if (mx == 0.0) return 0.0;
   uint64_t be = (d2b(mx) >> 52) & 0x7ff;  // frexp exponent e = be - 1022; scale = 2^-e
   double scale = b2d((uint64_t)(2045 - be) << 52);
+  double inv_scale = b2d((uint64_t)(be + 1) << 52);  // 2^e: dividing by the power of two `scale` == multiplying by it
   double csum = 1.0, f1 = 0.0, f2 = 0.0, f3 = 0.0, x, t, hi, lo, old, h;
   x = v0 * scale;
   t = x * T27; hi = t - (t - x); lo = x - hi;
@@ -174,7 +175,7 @@ RPP_HD static inline double py_hypot(double a, double b) {
   x = -2.0 * hi * lo; old = csum; csum += x; f2 += (old - csum) + x;
   x = -lo * lo; old = csum; csum += x; f3 += (old - csum) + x;
   x = csum - 1.0 + (f1 + f2 + f3);
-  return (h + x / (2.0 * h)) / scale;
+  return (h + x / (2.0 * h)) * inv_scale;
 }
 
 // float ** 2 as CPython computes it: libm pow(|x|, 2.0) (floatobject.c float_pow);

@@ -112,6 +112,14 @@ struct Sh {
 
 __device__ __forceinline__ int roundup_i(int a, int b) { return (a + b - 1) / b * b; }
 
+// 16-byte streaming load of two adjacent nodes.  The node arrays are re-read from HBM every iteration (the
+// per-GPU working set is far larger than L2 / Infinity Cache), so they are loaded non-temporally to leave the
+// caches to the small hot data: libm tables, child lists, candidate gathers.
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2d stream2(const double* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p));
+}
+
 // ---------------------------------------------------------------------------
 // block-wide (value, index) argmin with lowest-index tie break; `second` is the
 // smallest value held by any element other than the winner (for the filter).
@@ -175,12 +183,12 @@ __device__ __forceinline__ void scan_nearest(const double* __restrict__ x, const
   double best = rpp::dinf(), second = rpp::dinf();
   int bidx = 0x7fffffff;
   for (int base = ws; base < we && base < n; base += WAVE_STRIDE) {
-    double2 xv[UNROLL], yv[UNROLL];
+    v2d xv[UNROLL], yv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const int i0 = base + u * 128 + lane * 2;
-      xv[u] = *reinterpret_cast<const double2*>(x + i0);
-      yv[u] = *reinterpret_cast<const double2*>(y + i0);
+      xv[u] = stream2(x + i0);
+      yv[u] = stream2(y + i0);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
@@ -220,12 +228,12 @@ __device__ __forceinline__ int scan_hits(const double* __restrict__ x, const dou
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int cnt = 0;
   for (int base = ws; base < we && base < n; base += WAVE_STRIDE) {
-    double2 xv[UNROLL], yv[UNROLL];
+    v2d xv[UNROLL], yv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const int i0 = base + u * 128 + lane * 2;
-      xv[u] = *reinterpret_cast<const double2*>(x + i0);
-      yv[u] = *reinterpret_cast<const double2*>(y + i0);
+      xv[u] = stream2(x + i0);
+      yv[u] = stream2(y + i0);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
@@ -274,12 +282,12 @@ __device__ __forceinline__ int scan_fused(const double* __restrict__ x, const do
   double best = rpp::dinf(), second = rpp::dinf();
   int bidx = 0x7fffffff;
   for (int base = ws; base < we && base < n; base += WAVE_STRIDE) {
-    double2 xv[UNROLL], yv[UNROLL];
+    v2d xv[UNROLL], yv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
       const int i0 = base + u * 128 + lane * 2;
-      xv[u] = *reinterpret_cast<const double2*>(x + i0);
-      yv[u] = *reinterpret_cast<const double2*>(y + i0);
+      xv[u] = stream2(x + i0);
+      yv[u] = stream2(y + i0);
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {

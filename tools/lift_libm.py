@@ -92,6 +92,8 @@ class Lifter:
         m = re.search(r"\.rodata\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", sec)
         self.ro_va, self.ro_off, self.ro_sz = (int(x, 16) for x in m.groups())
         self.tables = {}  # base vaddr -> max offset seen (bytes)
+        self.tabdefs = []  # (base, size) of the lookup tables, when known (enables direct, batched table loads)
+        self.prov = {}     # instruction address -> {base register: table base} (pointer provenance at that point)
 
     def rd64(self, va):
         off = va - self.ro_va + self.ro_off
@@ -148,7 +150,16 @@ class Lifter:
             e.append("(%s*%sULL)" % (self.rreg(idx[1:], 64), sc))
         if disp:
             e.append("(uint64_t)(int64_t)(%d)" % disp)
-        return ("dyn", "(" + "+".join(e) + ")")
+        expr = "(" + "+".join(e) + ")"
+        pv = self.prov.get(addr, {})
+        t = None
+        if base and REGMAP[base[1:]][1] == 64:
+            t = pv.get(REGMAP[base[1:]][0])
+        if t is None and idx and sc == "1" and REGMAP[idx[1:]][1] == 64:
+            t = pv.get(REGMAP[idx[1:]][0])
+        if t is not None:
+            return ("tab", t, expr)
+        return ("dyn", expr)
 
     # ---------------- register access -----------------
     def rreg(self, name, want=None):
@@ -190,6 +201,8 @@ class Lifter:
             return "((%s)0x%xULL)" % (UT[w], v)
         if k[0] == "stk":
             return "((%s)STK%d(%d))" % (UT[w], w, k[1])
+        if k[0] == "tab":
+            return "((%s)ROMT(%x, %s))" % (UT[w], k[1], k[2])
         return "((%s)ROM%d(%s))" % (UT[w], w, k[1])
 
     def iwrite(self, op, w, val, addr):
@@ -210,6 +223,8 @@ class Lifter:
             return "0x%016xULL" % self.rd64(k[1])
         if k[0] == "stk":
             return "STK64(%d)" % k[1]
+        if k[0] == "tab":
+            return "ROMT(%x, %s)" % (k[1], k[2])
         return "ROM64(%s)" % k[1]
 
     def xread32(self, op, addr):
@@ -220,6 +235,8 @@ class Lifter:
             return "0x%08xU" % self.rd32(k[1])
         if k[0] == "stk":
             return "STK32(%d)" % k[1]
+        if k[0] == "tab":
+            return "((uint32_t)ROMT(%x, %s))" % (k[1], k[2])
         return "ROM32(%s)" % k[1]
 
     def width_of(self, mn, ops):
@@ -373,6 +390,8 @@ class Lifter:
                 return [self.wreg(ops[1][1:], "0x%xULL" % k[1])]
             if k[0] == "stk":  # address of a stack slot: only ever an out-parameter of an (out-of-domain) call
                 return [self.wreg(ops[1][1:], "0xdead0000ULL + %d" % k[1])]
+            if k[0] == "tab":
+                return [self.wreg(ops[1][1:], k[2])]
             assert k[0] == "dyn", (hex(addr), self.ins[addr])
             return [self.wreg(ops[1][1:], k[1])]
         if mn in ("add", "sub", "and", "or", "xor", "cmp", "test", "addq", "subq", "andl", "cmpl", "testb", "cmpq",
@@ -463,6 +482,102 @@ class Lifter:
             "s": "sf", "ns": "!sf", "p": "pf", "np": "!pf",
         }[cc]
 
+
+    # ---------------- pointer provenance (which lookup table a register points into) -----------------
+    def table_of(self, va):
+        for (b, sz) in self.tabdefs:
+            if b <= va < b + sz:
+                return b
+        return None
+
+    def dest_gpr(self, mn, ops):
+        """(base register, width) written by the instruction, or None."""
+        if mn == "cltq":
+            return ("rax", 64)
+        if mn in ("cqto", "cltd", "cdq"):
+            return ("rdx", 64)
+        if not ops:
+            return None
+        if mn.startswith(("cmp", "test", "j", "call", "ret", "nop", "push", "vcomis", "vucomis", "comis", "ucomis",
+                          "vstmxcsr", "vldmxcsr", "endbr")) or mn == "bt":
+            return None
+        d = ops[-1]
+        if d.startswith("%") and not d.startswith("%xmm") and not d.startswith("%fs") and d[1:] in REGMAP:
+            r, w, _ = REGMAP[d[1:]]
+            return (r, w)
+        return None
+
+    def transfer(self, addr, st):
+        mn, ops = self.parse(addr)
+        st = dict(st)
+        dg = self.dest_gpr(mn, ops)
+        if dg is None:
+            return st
+        r, w = dg
+        newv = None
+        if w == 64:
+            if mn == "lea":
+                k = None
+                op = ops[0]
+                m = re.match(r"^(-?0x[0-9a-f]+|-?\d+)?\((%\w+)?(?:,(%\w+),(\d))?\)$", op)
+                if m:
+                    disp = int(m.group(1), 0) if m.group(1) else 0
+                    base, idx, sc = m.group(2), m.group(3), m.group(4)
+                    if base == "%rip":
+                        newv = self.table_of(self.nxt[addr] + disp)
+                    else:
+                        if base and base[1:] in REGMAP and REGMAP[base[1:]][1] == 64:
+                            newv = st.get(REGMAP[base[1:]][0])
+                        if newv is None and idx and sc == "1" and REGMAP[idx[1:]][1] == 64:
+                            newv = st.get(REGMAP[idx[1:]][0])
+            elif mn in ("mov", "movq") and ops[0].startswith("%") and ops[0][1:] in REGMAP and REGMAP[ops[0][1:]][1] == 64:
+                newv = st.get(REGMAP[ops[0][1:]][0])
+            elif mn in ("add", "addq"):
+                newv = st.get(r)
+                if newv is None and ops[0].startswith("%") and ops[0][1:] in REGMAP and REGMAP[ops[0][1:]][1] == 64:
+                    newv = st.get(REGMAP[ops[0][1:]][0])
+        if newv is None:
+            st.pop(r, None)
+        else:
+            st[r] = newv
+        return st
+
+    def analyse_provenance(self, entry, end, seen):
+        self.prov = {}
+        if not self.tabdefs:
+            return
+        succ = {}
+        for a in seen:
+            mn, ops = self.parse(a)
+            sc = []
+            if mn == "ret" or mn == "call":
+                pass
+            elif mn.startswith("j"):
+                tgt = int(ops[0], 16)
+                if entry <= tgt < end and tgt in seen:
+                    sc.append(tgt)
+                if mn != "jmp" and self.nxt[a] in seen:
+                    sc.append(self.nxt[a])
+            elif self.nxt[a] in seen:
+                sc.append(self.nxt[a])
+            succ[a] = sc
+        IN = {entry: {}}
+        work = [entry]
+        while work:
+            a = work.pop()
+            out = self.transfer(a, IN[a])
+            for t in succ[a]:
+                if t not in IN:
+                    IN[t] = dict(out)
+                    work.append(t)
+                else:
+                    cur = IN[t]
+                    merged = {k: v for k, v in cur.items() if out.get(k) == v}
+                    if merged != cur:
+                        IN[t] = merged
+                        work.append(t)
+        self.prov = IN
+
     # ---------------- whole function -----------------
     def lift(self, name, entry, end, nargs):
         region = (entry, end)
@@ -484,6 +599,7 @@ class Lifter:
                     if mn == "jmp":
                         break
                 a = self.nxt[a]
+        self.analyse_provenance(entry, end, seen)
         body = []
         addrs = sorted(seen)
         for i, a in enumerate(addrs):
@@ -558,6 +674,7 @@ MACROS = r"""
 #define SETSTK8(o, v) do { uint32_t s_ = ((o) & 3) * 8; stk[(o) >> 2] = (stk[(o) >> 2] & ~(0xffu << s_)) | ((uint32_t)(uint8_t)(v) << s_); } while (0)
 #define STK8(o) ((uint8_t)(stk[(o) >> 2] >> (((o) & 3) * 8)))
 #define ROM64(a) rpp_glibc_rom64(a)
+#define ROMT(t, a) (rpp_glibc_rom_##t[(((a) - 0x##t##ULL) >> 3)])
 #define ROM32(a) ((uint32_t)rpp_glibc_rom64(a))
 """
 
@@ -577,6 +694,7 @@ UNMACROS = """
 #undef SETSTK8
 #undef STK8
 #undef ROM64
+#undef ROMT
 #undef ROM32
 """
 
@@ -585,22 +703,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libm", default="/lib/x86_64-linux-gnu/libm.so.6")
     ap.add_argument("--out", default="robotics-path-planning_amd/csrc/glibc235_fma_math.h")
-    ap.add_argument("--tables", default=None,
+    ap.add_argument("--tables", default="aeb80:dc0,af960:870,b1b20:1048,be0e0:34b8",
                     help="comma list base:size (hex) of lookup tables reached through lea; printed when omitted")
     a = ap.parse_args()
     L = Lifter(a.libm)
     sha = hashlib.sha256(L.blob).hexdigest()
     ver = subprocess.run(["ldd", "--version"], capture_output=True, text=True).stdout.split("\n")[0]
+    tabs = []
+    if a.tables is not None:
+        for t in a.tables.split(","):
+            b, s = t.split(":")
+            tabs.append((int(b, 16), int(s, 16)))
+    L.tabdefs = tabs
     bodies = []
     for name, entry, end, nargs in FUNCS:
         bodies.append(L.lift(name, entry, end, nargs))
     if a.tables is None:
         print("lea targets:", " ".join(hex(t) for t in sorted(L.tables)))
         return 1
-    tabs = []
-    for t in a.tables.split(","):
-        b, s = t.split(":")
-        tabs.append((int(b, 16), int(s, 16)))
     rom = ["// lookup tables (copied as data from .rodata of the libm named above)"]
     sel = []
     for (b, s) in tabs:
