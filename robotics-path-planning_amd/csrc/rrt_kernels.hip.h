@@ -719,7 +719,8 @@ __device__ __forceinline__ int best_goal_node(const Ctx& c, Inst* I, const doubl
 }
 
 // get_random_node / get_random_node_sobol (rrt_04:1132-1153), lane 0; result in sh.rx, sh.ry
-__device__ __forceinline__ void draw_sample(const Ctx& c, Sh& sh, rpp::Sobol& sob, double gx, double gy) {
+template <class SH>
+__device__ __forceinline__ void draw_sample(const Ctx& c, SH& sh, rpp::Sobol& sob, double gx, double gy) {
   double rx, ry;
   if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {
     if (c.sampler == 1 && c.algo == 1) {

@@ -14,6 +14,7 @@
 
 #include "../../include/rrtx.h"
 #include "rrt_kernels.hip.h"
+#include "rrt_star_v2.hip.h"
 
 using rppk::Ctx;
 using rppk::Inst;
@@ -283,6 +284,29 @@ int rrtx_plan(rrtx_handle* h) {
   double kms = 0.0;
   int64_t launches = 0;
   std::vector<Result> res(B);
+  // RRT* with search_until_max_iter: the latency-lean iteration kernel runs every iteration; the general kernel
+  // below then only performs the final goal search (rrt_04:1080-1084).  RRTX_KERNEL=v1 forces the general kernel.
+  const char* kv = getenv("RRTX_KERNEL");
+  const bool use_v2 = c.algo == RRTX_ALGO_RRT_STAR && c.until_max && !(kv && !strcmp(kv, "v1"));
+  if (use_v2) {
+    // workgroup shape: 128 threads per instance once more than 1024 instances want to be resident (8 per CU)
+    int tpb = (B > 1280 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
+    if (const char* e = getenv("RRTX_TPB")) tpb = (atoi(e) == 128 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
+    for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->chunk_iters) {
+      HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+      if (tpb == 128)
+        hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
+      else
+        hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->chunk_iters);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      float ms = 0.f;
+      HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+      kms += ms;
+      launches++;
+    }
+  }
   for (;;) {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);

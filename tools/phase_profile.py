@@ -24,8 +24,9 @@ s = h.get_stats()
 ph = h.get_phase_cycles()
 names = {0: "sample", 1: "nearest scan", 2: "ext steer", 3: "ext collision", 4: "near scan", 5: "exact+dedup",
          6: "choose edges", 7: "choose cost/min", 8: "rewire edges", 9: "rewire seq+propagate+append", 11: "bookkeeping",
-         12: "goal", 15: "loop"}
-tot = float(ph.sum())
+         12: "goal", 15: "loop",
+         13: "  (choose edges: hypot only)", 14: "  (choose edges: atan2 only)", 10: "  (choose edges: cos|sin + stores)"}
+tot = float(ph.sum() - ph[13] - ph[14] - ph[10])
 print("instances", B, "max_iter", it, "kernel_ms", s["kernel_ms"], "alg GB/s", s["algorithmic_bytes"] / 1e6 / s["kernel_ms"])
 for k in sorted(names):
     print("  %-30s %6.2f%%  %.1f cycles/iter/inst" % (names[k], 100.0 * ph[k] / tot if tot else 0, ph[k] / max(s["iterations"], 1)))
