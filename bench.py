@@ -65,11 +65,14 @@ def main():
     ngpu = max(world, 1)
     device = local_rank
 
+    import importlib
     import rrt_amd
+    sharding = importlib.import_module("robotics-path-planning_amd.sharding")
     A = rrt_amd._abi
     kw = util.c2_kwargs(a.max_iter, m=a.obstacles)
     B = a.instances
-    seeds = [rank * B + i + 1 for i in range(B)]
+    seeds = sharding.shard_seeds(rank, B)          # rank r owns seeds r*B+1 .. (r+1)*B, no exchange while planning
+    cuda = torch.device("cuda", local_rank) if dist is not None else None
 
     def make_handle(max_iter):
         h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
@@ -114,11 +117,7 @@ def main():
         launches += s["launches"]
         # time guard (all ranks take the same decision: the slowest rank's clock decides)
         spent, last = time.perf_counter() - t0, time.perf_counter() - ts
-        go = 1 if (spent + last <= a.max_seconds) else 0
-        if dist is not None:
-            g = torch.tensor([go], dtype=torch.int32, device="cuda")
-            dist.all_reduce(g, op=dist.ReduceOp.MIN)
-            go = int(g.item())
+        go = sharding.all_agree_min(dist, 1 if (spent + last <= a.max_seconds) else 0, cuda)
         if not go:
             break
     sync_all()
@@ -126,21 +125,10 @@ def main():
     pc, nn, st = h.get_results()
     stats = h.get_stats()
 
-    # ---- cross-rank: max time, summed work, RCCL gather of the result table
-    tot_edges_u, tot_edges_r, tmax = edges_u, edges_r, dt
-    all_pc, all_nn = pc, nn
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
-        w = torch.tensor([edges_u, edges_r], dtype=torch.int64, device="cuda")
-        dist.all_reduce(w, op=dist.ReduceOp.SUM)
-        tot_edges_u, tot_edges_r = int(w[0].item()), int(w[1].item())
-        rec = torch.from_numpy(np.stack([pc, nn.astype(np.float64)], axis=1)).cuda()   # per-instance result records
-        out = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(out, rec)                                                       # the path-cost gather (RCCL)
-        allr = torch.cat(out).cpu().numpy()
-        all_pc, all_nn = allr[:, 0], allr[:, 1].astype(np.int64)
+    # ---- cross-rank: max time, summed work, RCCL gather of the result table (the only data collective)
+    tmax = sharding.reduce_max(dist, dt, cuda)
+    tot_edges_u, tot_edges_r = sharding.reduce_sum_int(dist, [edges_u, edges_r], cuda)
+    all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda)
 
     if rank == 0:
         finite = np.isfinite(all_pc)
