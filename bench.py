@@ -39,7 +39,7 @@ def main():
                     help="planning instances per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
     ap.add_argument("--obstacles", type=int, default=50)
-    ap.add_argument("--cpu-iters", type=int, default=30000, help="iterations of the CPU baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
                     help="iterations of a warm-up step (0 = same as a timed step); a warm-up only has to page in the "
@@ -133,12 +133,22 @@ def main():
     if rank == 0:
         finite = np.isfinite(all_pc)
         value = tot_edges_u / tmax
-        # roofline.achieved follows the contract: SURVEY.md 8(d)'s per-iteration figure (32*n + 48*k + 24*M + 28, two
-        # node-array scans per iteration) x iterations / kernel time.  This implementation serves both queries of an
-        # iteration from ONE pass over the node arrays, so the bytes it actually has to move are about half of that
-        # figure: `achieved_single_pass` (and the PMC `traffic`) are the physical rates.
-        achieved = (alg_bytes2 / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
-        achieved_sp = (alg_bytes / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+        # roofline.achieved = bytes the algorithm as implemented must move (ONE pass over the node arrays per iteration
+        # serves both the near-ball query of iteration i and the nearest query of i+1: 16*n + 48*k + 24*M + 28 per
+        # iteration) / HIP-event time of the planner kernel.  SURVEY.md 8(d) wrote the formula for two separate scans
+        # (32*n + ...): that figure is reported next to it as `survey_8d_two_scan_*`.
+        achieved = (alg_bytes / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+        achieved_2s = (alg_bytes2 / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
+        traffic = None
+        traffic_note = None
+        try:   # PMC traffic of the same workload, measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if tj["config"]["instances_per_gpu"] == B and tj["config"]["max_iter"] == a.max_iter \
+                    and tj["config"]["obstacles"] == a.obstacles:
+                traffic = tj["hbm_bytes_per_step"] / 1e9 / (kernel_ms / 1e3 / max(steps_done, 1))
+                traffic_note = "HBM bytes/step %.4g from %s" % (tj["hbm_bytes_per_step"], "profiles/r1_traffic.json")
+        except Exception:  # noqa: BLE001
+            pass
         line = {
             "metric": "RRT* collision-checked edge expansions/sec (unique edges evaluated on device), "
                       "%d-iteration trees" % a.max_iter,
@@ -156,14 +166,14 @@ def main():
             "paths_found": int(finite.sum()), "instances_total": int(len(all_pc)),
             "iterations_per_s": iters * ngpu / tmax,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "rppk::rrt_plan_kernel", "launches": launches,
-                         "algorithmic_bytes_per_step": alg_bytes2 / max(steps_done, 1),
-                         "achieved_single_pass": achieved_sp, "frac_single_pass": achieved_sp / 8000.0,
-                         "single_pass_bytes_per_step": alg_bytes / max(steps_done, 1),
-                         "note": "achieved = SURVEY 8(d) two-scan algorithmic bytes / kernel time; the kernel reads each "
-                                 "node once per iteration for both queries (fused pass), so physical traffic is ~half: "
-                                 "see achieved_single_pass and profiles/ PMC traffic",
+                         "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
+                         "traffic_note": traffic_note,
+                         "survey_8d_two_scan_GBps": achieved_2s, "survey_8d_two_scan_frac": achieved_2s / 8000.0,
+                         "note": "achieved = single-pass algorithmic bytes (16*n per iteration: the near pass of "
+                                 "iteration i also answers the nearest query of i+1) / kernel time; "
+                                 "survey_8d_two_scan_* applies SURVEY 8(d)'s two-scan formula (32*n) to the same run",
                          "kernel_ms_per_step": kernel_ms / max(steps_done, 1)},
             "steps_requested": a.steps, "warmup_max_iter": a.warmup_max_iter or a.max_iter,
         }
