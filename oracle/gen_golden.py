@@ -187,3 +187,86 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------------------------------------ rrt_07
+def run_rrt07(mod, name, obstacles, start, goal, rand_area, expand_dis, goal_sample_rate, max_iter, sobol, seed):
+    """Informed RRT* (rrt_07:1027-1285).  Also stores the rotation matrix C the reference builds with numpy's SVD
+    (rrt_07:1061-1068): the product takes it from the host exactly like this."""
+    import math
+    ref_loader.reset_sobol(mod)
+    random.seed(seed)
+    rrt = mod.RRT(start=start, goal=goal, obstacle_list=obstacles, rand_area=rand_area, expand_dis=expand_dis,
+                  goal_sample_rate=goal_sample_rate, max_iter=max_iter, sobol_sampler=sobol)
+    tr = {"rnd_x": [], "rnd_y": [], "nearest": [], "n_near": []}
+    cm = {}
+    o_is = rrt.informed_sample
+    o_near = mod.RRT.get_nearest_list_index
+    o_fn = rrt.find_near_nodes
+
+    def is_hook(c_max, c_min, x_center, c):
+        cm["c"] = np.array(c, dtype=np.float64)
+        cm["c_min"] = float(c_min)
+        cm["x_center"] = np.array(x_center, dtype=np.float64)
+        r = o_is(c_max, c_min, x_center, c)
+        tr["rnd_x"].append(float(r[0]))
+        tr["rnd_y"].append(float(r[1]))
+        return r
+
+    def near_hook(nodes, rnd):
+        i = o_near(nodes, rnd)
+        tr["nearest"].append(i)
+        return i
+
+    def fn_hook(new_node):
+        r = o_fn(new_node)
+        tr["n_near"].append(len(r))
+        return r
+    rrt.informed_sample = is_hook
+    rrt.get_nearest_list_index = near_hook
+    rrt.find_near_nodes = fn_hook
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = rrt.informed_rrt_star_search(animation=False)
+    dt = time.time() - t0
+    x, y, cost, parent = tree_arrays(rrt.node_list, int_parent=True)
+    state = random.getstate()
+    out = dict(
+        algo="informed", seed=seed, obstacles=np.array(obstacles, dtype=np.float64),
+        start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
+        rand_area=np.array(rand_area, dtype=np.float64), expand_dis=expand_dis, goal_sample_rate=goal_sample_rate,
+        max_iter=max_iter, sobol=int(bool(sobol)), rot_c=cm["c"], c_min=cm["c_min"], x_center=cm["x_center"],
+        x=x, y=y, cost=cost, parent=parent,
+        path=np.array(path if path is not None else [], dtype=np.float64).reshape(-1, 2),
+        path_found=int(path is not None), ref_seconds=dt,
+        path_len=float(mod.RRT.get_path_len(path)) if path is not None else float("inf"),
+        rng_pos_after=state[1][624], rng_word0_after=np.uint32(state[1][0]),
+        sobol_index_after=getattr(rrt, "sobol_inter_", 0),
+        tr_rnd_x=np.array(tr["rnd_x"]), tr_rnd_y=np.array(tr["rnd_y"]),
+        tr_nearest=np.array(tr["nearest"], dtype=np.int32), tr_n_near=np.array(tr["n_near"], dtype=np.int32),
+    )
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-28s nodes=%d path=%s len=%r  %.2fs" % (name, len(x), None if path is None else len(path), out["path_len"], dt))
+
+
+def main07(only=""):
+    os.makedirs(OUT, exist_ok=True)
+    m07 = ref_loader.load("rrt_07")
+    drv = dict(obstacles=DRIVER_OBST, start=[0.0, 0.0], goal=[6.0, 10.0], rand_area=[-2, 15], expand_dis=0.5,
+               goal_sample_rate=10)
+    jobs = []
+    for seed, it, sob in ((42, 200, 0), (42, 200, 1), (42, 2000, 0), (7, 1200, 0), (3, 1200, 1), (11, 800, 0), (5, 600, 0)):
+        jobs.append(("rrt07_drv_%s_s%d_it%d" % ("sobol" if sob else "mt", seed, it), dict(drv, max_iter=it, sobol=sob, seed=seed)))
+    # C3-style synthetic map (SURVEY 8d): map_seed 11, 200 circles, radii U(0.3,1.5), Sobol sampler
+    c3 = dict(obstacles=synth_map(11, 200, 0.3, 1.5), start=[2, 2], goal=[98, 98], rand_area=[0, 100], expand_dis=0.5,
+              goal_sample_rate=10)
+    for seed, it, sob in ((1, 3000, 1), (2, 3000, 0)):
+        jobs.append(("rrt07_c3_%s_s%d_it%d" % ("sobol" if sob else "mt", seed, it), dict(c3, max_iter=it, sobol=sob, seed=seed)))
+    # a denser, closer problem on the C3 obstacle family so that a path (and the informed phase) is reached quickly
+    c3b = dict(obstacles=synth_map(11, 200, 0.3, 1.5), start=[40, 40], goal=[50, 52], rand_area=[30, 62], expand_dis=0.5,
+               goal_sample_rate=10)
+    for seed, it, sob in ((3, 700, 1), (4, 700, 0)):
+        jobs.append(("rrt07_c3near_%s_s%d_it%d" % ("sobol" if sob else "mt", seed, it), dict(c3b, max_iter=it, sobol=sob, seed=seed)))
+    for n, kw in jobs:
+        if n.startswith(only):
+            run_rrt07(m07, n, **kw)

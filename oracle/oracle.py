@@ -122,3 +122,61 @@ def plan(algo="rrt_star", start=(0, 0), goal=(6, 10), obstacles=(), rand_area=(-
         t = o.tr_n
         res.update(tr_rnd_x=trx[:t].copy(), tr_rnd_y=try_[:t].copy(), tr_nearest=trn[:t].copy(), tr_n_near=trk[:t].copy())
     return res
+
+
+def rotation_to_world(start, goal):
+    """The matrix `c` of rrt_07:1054-1068, computed with numpy exactly as the reference does (SVD of a1 . e1^T)."""
+    import math
+    c_min = math.hypot(start[0] - goal[0], start[1] - goal[1])
+    a1 = np.array([[(goal[0] - start[0]) / c_min], [(goal[1] - start[1]) / c_min], [0]])
+    id1_t = np.array([1.0, 0.0, 0.0]).reshape(1, 3)
+    m = a1 @ id1_t
+    u, s, vh = np.linalg.svd(m, True, True)
+    return u @ np.diag([1.0, 1.0, np.linalg.det(u) * np.linalg.det(np.transpose(vh))]) @ vh
+
+
+def plan_informed(start, goal, obstacles, rand_area, expand_dis=0.5, goal_sample_rate=10, max_iter=200, sobol=False,
+                  seed=None, rng=None, exact_pow=True, trace=False, rot_c=None):
+    """One RRT.informed_rrt_star_search() call of rrt_07 on the oracle."""
+    L = lib()
+    L.orc_plan_informed.restype = C.c_int
+    p = Params()
+    p.algo = 2
+    p.goal_sample_rate, p.max_iter = int(goal_sample_rate), int(max_iter)
+    p.sobol, p.exact_pow = int(bool(sobol)), int(bool(exact_pow))
+    p.start[0], p.start[1] = float(start[0]), float(start[1])
+    p.goal[0], p.goal[1] = float(goal[0]), float(goal[1])
+    p.rand_min, p.rand_max = float(rand_area[0]), float(rand_area[1])
+    p.expand_dis = float(expand_dis)
+    obst = np.ascontiguousarray(np.array(obstacles, dtype=np.float64).reshape(-1, 3))
+    if rng is None:
+        rng = mt_from_seed(seed)
+    if rot_c is None:
+        rot_c = rotation_to_world([float(start[0]), float(start[1])], [float(goal[0]), float(goal[1])])
+    rc_ = np.ascontiguousarray(np.array(rot_c, dtype=np.float64).reshape(9))
+    cap = int(max_iter) + 2
+    x = np.zeros(cap); y = np.zeros(cap); cost = np.zeros(cap); parent = np.zeros(cap, dtype=np.int32)
+    path = np.zeros((cap + 2, 2))
+    o = Out()
+    o.x, o.y, o.cost, o.parent = x.ctypes.data, y.ctypes.data, cost.ctypes.data, parent.ctypes.data
+    o.cap = cap
+    o.path_xy, o.path_cap = path.ctypes.data, cap + 2
+    if trace:
+        trx = np.zeros(max_iter); try_ = np.zeros(max_iter)
+        trn = np.zeros(max_iter, dtype=np.int32); trk = np.zeros(max_iter, dtype=np.int32)
+        o.tr_rnd_x, o.tr_rnd_y, o.tr_nearest, o.tr_n_near = trx.ctypes.data, try_.ctypes.data, trn.ctypes.data, trk.ctypes.data
+        o.tr_cap = int(max_iter)
+    st = Stats()
+    cb = C.c_double()
+    rc = L.orc_plan_informed(C.byref(p), obst.ctypes.data_as(C.c_void_p), C.c_int(len(obst)),
+                             rc_.ctypes.data_as(C.c_void_p), C.byref(rng), C.byref(o), C.byref(st), C.byref(cb))
+    if rc != 0:
+        raise RuntimeError("orc_plan_informed failed: %d" % rc)
+    n = o.n
+    res = dict(x=x[:n].copy(), y=y[:n].copy(), cost=cost[:n].copy(), parent=parent[:n].copy(),
+               path=path[:o.path_n].copy() if o.path_n else None, c_best=cb.value,
+               stats={k: getattr(st, k) for k, _ in Stats._fields_}, rng=rng)
+    if trace:
+        t = o.tr_n
+        res.update(tr_rnd_x=trx[:t].copy(), tr_rnd_y=try_[:t].copy(), tr_nearest=trn[:t].copy(), tr_n_near=trk[:t].copy())
+    return res
