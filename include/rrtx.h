@@ -7,6 +7,7 @@
  * binding on the reference side calls in place of the body of
  *   10_path_planning_01_rrt_01_simple.py   RRT.planning            :71-101
  *   10_path_planning_01_rrt_04_rrt_star.py RRT.planning            :1036-1084
+ *   10_path_planning_01_rrt_07_informed_rrt_star.py RRT.informed_rrt_star_search :1044-1108
  * Each entry point names the reference interface it replaces.  Plain pointers
  * and sizes only; the caller owns every host buffer, the library owns device
  * memory behind the opaque handle.  Every function returns 0 or a negative
@@ -35,7 +36,8 @@ enum {
 };
 
 enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
-       RRTX_ALGO_RRT_STAR = 1   /* rrt_04 RRT.planning :1036-1084 */ };
+       RRTX_ALGO_RRT_STAR = 1,  /* rrt_04 RRT.planning :1036-1084 */
+       RRTX_ALGO_INFORMED = 2   /* rrt_07 RRT.informed_rrt_star_search :1044-1108 */ };
 enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
        RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
 
@@ -62,7 +64,11 @@ typedef struct rrtx_params {
   double play_area[4];           /* xmin xmax ymin ymax (rrt_04:944-949) */
   double robot_radius;           /* rrt_04:991 */
   double connect_circle_dist;    /* rrt_04:998 */
-  double reserved_d[8];
+  /* RRTX_ALGO_INFORMED only: upper-left 2x2 of the rotation `c` (numpy SVD, rrt_07:1061-1068), row major, and
+   * c_min = math.hypot(start - goal) (rrt_07:1054); the host computes both exactly as the reference does. */
+  double informed_rot[4];
+  double informed_c_min;
+  double reserved_d[3];
 } rrtx_params;
 
 /* Aggregate counters over all instances of the last rrtx_plan(). */

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
 RRTX_ABI_VERSION = 1
-ALGO_RRT, ALGO_RRT_STAR = 0, 1
+ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED = 0, 1, 2
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
 ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC = 1, 2, 4, 8
 ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
@@ -34,7 +34,8 @@ class Params(C.Structure):
                 ("rand_min", C.c_double), ("rand_max", C.c_double),
                 ("expand_dis", C.c_double), ("path_resolution", C.c_double),
                 ("play_area", C.c_double * 4), ("robot_radius", C.c_double),
-                ("connect_circle_dist", C.c_double), ("reserved_d", C.c_double * 8)]
+                ("connect_circle_dist", C.c_double), ("informed_rot", C.c_double * 4),
+                ("informed_c_min", C.c_double), ("reserved_d", C.c_double * 3)]
 
 
 class Stats(C.Structure):
@@ -100,7 +101,7 @@ class Handle:
 
     def __init__(self, algo, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
                  play_area=None, robot_radius=0.0, sampler=SAMPLER_MT, connect_circle_dist=50.0,
-                 search_until_max_iter=False, n_instances=1, device=0):
+                 search_until_max_iter=False, n_instances=1, device=0, informed_rot=None, informed_c_min=0.0):
         self.L = load()
         p = Params()
         p.abi_version = RRTX_ABI_VERSION
@@ -120,6 +121,10 @@ class Handle:
                 p.play_area[i] = float(play_area[i])
         p.robot_radius = float(robot_radius)
         p.connect_circle_dist = float(connect_circle_dist)
+        if informed_rot is not None:
+            for i in range(4):
+                p.informed_rot[i] = float(informed_rot[i])
+        p.informed_c_min = float(informed_c_min)
         self.params = p
         self.n_instances = int(n_instances)
         self.max_iter = int(max_iter)

@@ -1,0 +1,446 @@
+// rrt_informed.hip.h -- Informed RRT* iteration kernel (gfx950).
+// Reference: /root/reference/src_path_planning/10_path_planning_01_rrt_07_informed_rrt_star.py  (rrt_07)
+//   informed_rrt_star_search :1044-1108, informed_sample :1145-1159, sample_unit_ball :1162-1171,
+//   sample_free_space(_sobol) :1173-1191, get_nearest_list_index :1210-1214, get_new_node :1216-1224,
+//   check_collision :1271-1276 -> check_segment_collision :1263-1269 -> distance_squared_point_to_segment :1249-1261,
+//   find_near_nodes :1137-1143, choose_parent :1110-1135, rewire :1232-1246, goal bookkeeping :1094-1103.
+//
+// Same structure and HBM layout as rrt_kernels.hip.h (one 256-thread workgroup per instance, streaming nearest and
+// near-ball passes over SoA x[], y[] with the exact-`**2` re-check, LDS obstacle tile).  Differences that matter:
+//  * fixed-length step, analytic point-to-segment collision (lanes over candidate x obstacle pairs);
+//  * near radius 50*sqrt(ln n / n), NOT capped: the candidate list reaches several hundred entries early on;
+//  * integer parents, no cost propagation; rewire(new -> node) re-derives exactly the (theta, d) choose_parent
+//    computed for (node -> new) -- hypot of the negated differences, atan2 of the same arguments -- so ONE
+//    collision test per candidate serves both (the reference evaluates it twice);
+//  * ellipsoidal informed sampling once a path exists: numpy's products are restated in the fused forms measured
+//    on the golden-generating box: 2-vector dot = fma(u1, w1, u0*w0); (3x3)@(3x1) row =
+//    fma(T_i0, x0, T_i1*x1); the rotation C (numpy SVD, rrt_07:1061-1068) is an input computed on the host.
+#pragma once
+#include "rrt_kernels.hip.h"
+
+namespace rppi {
+
+using rppk::Ctx;
+using rppk::Inst;
+using rppk::FILTER_EPS;
+
+constexpr int TPB = 256;
+constexpr int NW = TPB / 64;
+constexpr int MAX_OBS = rppk::MAX_OBS;
+constexpr int NUI = 512;   // distinct near candidates held in LDS
+
+struct ShI {
+  rpp::MT rng;
+  double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
+  int32_t uidx[NUI], ufree[NUI];
+  double uval[NUI], ux[NUI], uy[NUI], ucost[NUI], ud[NUI], uex[NUI], uey[NUI];
+  double cval[TPB];
+  int32_t cflag[TPB];
+  double red_best[NW], red_second[NW];
+  int32_t red_idx[NW], wave_cnt[NW], wave_start[NW];
+  double rx, ry, nx, ny, ex, ey, ncost, cbest, plen;
+  int32_t flag, nu, nvalid, overflow, ecoll, npar, nrw;
+};
+
+// numpy `u.dot(w)` for 2-vectors on the golden box: fma(u1, w1, u0*w0)
+__device__ __forceinline__ double np_dot2(double u0, double u1, double w0, double w1) {
+  return __builtin_fma(u1, w1, u0 * w0);
+}
+// distance_squared_point_to_segment (rrt_07:1249-1261)
+__device__ __forceinline__ double seg_dist2(double vx, double vy, double wx, double wy, double px, double py) {
+  if (vx == wx && vy == wy) {
+    const double a = px - vx, b = py - vy;
+    return np_dot2(a, b, a, b);
+  }
+  const double wv0 = wx - vx, wv1 = wy - vy;
+  const double l2 = np_dot2(wv0, wv1, wv0, wv1);
+  const double pv0 = px - vx, pv1 = py - vy;
+  const double tt = np_dot2(pv0, pv1, wv0, wv1) / l2;
+  double t = tt < 1.0 ? tt : 1.0;   // min(1, tt)
+  t = t > 0.0 ? t : 0.0;            // max(0, .)
+  const double pr0 = vx + t * wv0, pr1 = vy + t * wv1;
+  const double q0 = px - pr0, q1 = py - pr1;
+  return np_dot2(q0, q1, q0, q1);
+}
+
+// exact re-check + `.index` de-dup (rrt_07:1140-1142) into the candidate records (idx, d2, x, y, cost)
+__device__ __forceinline__ void build_candidates_i(const double* __restrict__ x, const double* __restrict__ y,
+                                                   const double* __restrict__ cost, double qx, double qy,
+                                                   double thr_exact, const int32_t* hits, int kraw, ShI& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) {
+    sh.nu = 0;
+    sh.nvalid = 0;
+  }
+  __syncthreads();
+  for (int base = 0; base < kraw; base += TPB) {
+    const int h = base + tid;
+    int idx = -1;
+    double v = 0.0, hx = 0.0, hy = 0.0;
+    bool valid = false;
+    if (h < kraw) {
+      idx = rppk::hit_at(hits, sh, h);
+      hx = x[idx];
+      hy = y[idx];
+      v = rpp::py_d2(hx - qx, hy - qy);
+      valid = v <= thr_exact;
+    }
+    const int nu = sh.nu;
+    bool cand = valid;
+    if (cand) {
+      for (int u = 0; u < nu; u++) {
+        if (sh.uval[u] == v) {
+          cand = false;
+          break;
+        }
+      }
+    }
+    sh.cval[tid] = v;
+    sh.cflag[tid] = cand ? 1 : 0;
+    __syncthreads();
+    bool first = cand;
+    if (cand) {
+      for (int t = 0; t < tid; t++) {
+        if (sh.cflag[t] && sh.cval[t] == v) {
+          first = false;
+          break;
+        }
+      }
+    }
+    const uint64_t mf = __ballot(first), mv = __ballot(valid);
+    if (lane == 0) {
+      sh.red_idx[w] = __popcll(mf);
+      atomicAdd(&sh.nvalid, __popcll(mv));
+    }
+    __syncthreads();
+    int off = nu;
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+      if (k < w) off += sh.red_idx[k];
+    int tot = nu;
+#pragma unroll
+    for (int k = 0; k < NW; k++) tot += sh.red_idx[k];
+    if (first) {
+      const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int p = off + __popcll(mf & lt_mask);
+      if (p < NUI) {
+        sh.uval[p] = v;
+        sh.uidx[p] = idx;
+        sh.ux[p] = hx;
+        sh.uy[p] = hy;
+        sh.ucost[p] = cost[idx];
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (tot > NUI) {
+        sh.overflow = 1;
+        tot = NUI;
+      }
+      sh.nu = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// rot: C[0][0], C[0][1], C[1][0], C[1][1]; xc: ellipse centre; c_min2 = c_min**2 (host libm)
+struct InformedArgs {
+  double rot[4];
+  double xc[2];
+  double c_min2;
+};
+
+__global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArgs ia, double* cbest_io, int iters) {
+  __shared__ ShI sh;
+  const int inst = blockIdx.x;
+  const int tid = threadIdx.x;
+  Inst* I = c.inst + inst;
+  if (I->status & 1) return;
+  const int64_t off = (int64_t)inst * c.stride;
+  double* __restrict__ x = c.x + off;
+  double* __restrict__ y = c.y + off;
+  double* __restrict__ cost = c.cost + off;
+  int32_t* parent = c.parent + off;
+  int32_t* hits = c.hits + off;
+  double* pathbuf = c.path_xy + (int64_t)inst * c.path_cap * 2;
+
+  for (int i = tid; i < 624; i += TPB) sh.rng.mt[i] = I->rng.mt[i];
+  for (int i = tid; i < c.m; i += TPB) {
+    sh.ox[i] = c.ox[i];
+    sh.oy[i] = c.oy[i];
+    sh.othr[i] = c.othr[i];
+  }
+  if (tid == 0) {
+    sh.rng.pos = I->rng.pos;
+    sh.overflow = 0;
+    sh.cbest = cbest_io[inst];
+  }
+  __syncthreads();
+  int n = I->n, it = I->it;
+  const double gx = I->goal[0], gy = I->goal[1], sx0 = I->start[0], sy0 = I->start[1];
+  const double E = c.expand_dis;
+  rpp::Sobol sob = I->sobol;
+  int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_sn = 0, s_ab = 0, s_ex = 0;
+  int stop = 0;
+
+  for (int step = 0; step < iters && it < c.max_iter && !stop; step++, it++) {
+    s_iter++;
+    // ---------------- informed_sample :1145-1159
+    if (tid == 0) {
+      double rx, ry;
+      const double cb = sh.cbest;
+      if (cb < rpp::dinf()) {
+        const double r0 = cb / 2.0;
+        const double r1 = __builtin_sqrt(rpp::py_sq(cb) - ia.c_min2) / 2.0;          // :1147
+        double a = rpp::mt_random(&sh.rng), b = rpp::mt_random(&sh.rng);            // sample_unit_ball :1162-1171
+        if (b < a) {
+          const double t = a;
+          a = b;
+          b = t;
+        }
+        const double ang = 2 * 3.141592653589793 * a / b;
+        const double s0 = b * rpp_glibc_cos(ang), s1 = b * rpp_glibc_sin(ang);
+        const double t00 = ia.rot[0] * r0, t01 = ia.rot[1] * r1, t10 = ia.rot[2] * r0, t11 = ia.rot[3] * r1;
+        rx = __builtin_fma(t00, s0, t01 * s1) + ia.xc[0];                            // np.dot(np.dot(c, rl), x_ball) + x_center :1151
+        ry = __builtin_fma(t10, s0, t11 * s1) + ia.xc[1];
+      } else if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {              // :1173-1191
+        if (c.sampler == 1) {
+          double q[2];
+          rpp::sobol_next(&sob, q);
+          rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);
+          ry = c.rand_min + q[1] * (c.rand_max - c.rand_min);
+        } else {
+          rx = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
+          ry = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
+        }
+      } else {
+        rx = gx;
+        ry = gy;
+      }
+      sh.rx = rx;
+      sh.ry = ry;
+    }
+    __syncthreads();
+    const double rx = sh.rx, ry = sh.ry;
+
+    // ---------------- nearest :1210-1214
+    int ni;
+    double gbest, gsecond;
+    rppk::scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
+    s_sn += n;
+    s_ab += 16 * (int64_t)n + 24 * (int64_t)c.m;
+    if (gbest != 0.0 && gsecond <= gbest * (1.0 + FILTER_EPS)) {
+      s_ex++;
+      const int kraw = rppk::scan_hits(x, y, n, rx, ry, gbest * (1.0 + FILTER_EPS), hits, sh);
+      double best = rpp::dinf(), second = rpp::dinf();
+      int bidx = 0x7fffffff;
+      for (int h = tid; h < kraw; h += TPB) {
+        const int idx = rppk::hit_at(hits, sh, h);
+        const double d = rpp::py_d2(x[idx] - rx, y[idx] - ry);
+        if (d < best || (d == best && idx < bidx)) {
+          best = d;
+          bidx = idx;
+        }
+      }
+      double gb2, gs2;
+      rppk::block_argmin(best, bidx, second, sh, gb2, ni, gs2);
+    }
+
+    // ---------------- steer :1080-1083 / get_new_node :1216-1224, extension edge :1085
+    if (tid == 0) {
+      const double qx = x[ni], qy = y[ni];
+      const double theta = rpp_glibc_atan2(ry - qy, rx - qx);
+      const double ct = rpp_glibc_cos(theta), st = rpp_glibc_sin(theta);
+      const double nx = qx + E * ct, ny = qy + E * st;
+      const double d = rpp::py_hypot(qx - nx, qy - ny);        // line_cost :1206
+      sh.nx = nx;
+      sh.ny = ny;
+      sh.ux[0] = qx;                                            // segment start (candidate slot 0 is free here)
+      sh.uy[0] = qy;
+      sh.ex = qx + ct * d;                                      // check_collision :1273-1274
+      sh.ey = qy + st * d;
+      sh.ncost = cost[ni] + E;                                  // :1222
+      sh.npar = ni;
+      sh.ecoll = 0;
+    }
+    __syncthreads();
+    const double nx = sh.nx, ny = sh.ny;
+    s_eu++;
+    s_er++;
+    for (int k = tid; k < c.m; k += TPB)
+      if (seg_dist2(sh.ux[0], sh.uy[0], sh.ex, sh.ey, sh.ox[k], sh.oy[k]) <= sh.othr[k]) sh.ecoll = 1;
+    __syncthreads();
+    const int accepted = !sh.ecoll;
+    int nnear = -1;
+
+    if (accepted) {
+      // ---------------- find_near_nodes :1137-1143  (n_node = len(node_list), radius not capped)
+      const double r2 = c.r2tab[n];
+      const int kraw = rppk::scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
+      s_sn += n;
+      build_candidates_i(x, y, cost, nx, ny, r2, hits, kraw, sh);
+      const int nu = sh.nu, nvalid = sh.nvalid;
+      nnear = nu;
+      s_nh += nvalid;
+      s_nu += nu;
+      s_ab += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
+      // ---------------- choose_parent :1110-1135 : (d, theta, end point) per candidate, then candidate x obstacle
+      for (int e = tid; e < nu; e += TPB) {
+        const double dx = nx - sh.ux[e], dy = ny - sh.uy[e];
+        const double d = rpp::py_hypot(dx, dy);
+        const double th = rpp_glibc_atan2(dy, dx);
+        sh.ud[e] = d;
+        sh.uex[e] = sh.ux[e] + rpp_glibc_cos(th) * d;
+        sh.uey[e] = sh.uy[e] + rpp_glibc_sin(th) * d;
+        sh.ufree[e] = 1;
+      }
+      __syncthreads();
+      for (int p = tid; p < nu * c.m; p += TPB) {
+        const int e = p / c.m, k = p - e * c.m;
+        if (seg_dist2(sh.ux[e], sh.uy[e], sh.uex[e], sh.uey[e], sh.ox[k], sh.oy[k]) <= sh.othr[k]) sh.ufree[e] = 0;
+      }
+      __syncthreads();
+      s_eu += nu;
+      s_er += nvalid;
+      if (nu > 0) {
+        double best = rpp::dinf(), second = rpp::dinf(), mn, gs;
+        int bidx = 0x7fffffff, sel;
+        for (int e = tid; e < nu; e += TPB) {
+          const double cc = sh.ufree[e] ? sh.ucost[e] + sh.ud[e] : rpp::dinf();   // :1120-1123
+          if (cc < best) {
+            best = cc;
+            bidx = e;
+          }
+        }
+        rppk::block_argmin(best, bidx, second, sh, mn, sel, gs);                  // first minimum :1125-1126
+        if (tid == 0 && mn < rpp::dinf()) {
+          sh.ncost = mn;                                                          // :1132-1133
+          sh.npar = sh.uidx[sel];
+        }
+        __syncthreads();
+      }
+      const double ncost = sh.ncost;
+      // ---------------- append :1091, rewire :1232-1246 (independent per candidate, same (theta, d) as above)
+      if (tid == 0) {
+        x[n] = nx;
+        y[n] = ny;
+        cost[n] = ncost;
+        parent[n] = sh.npar;
+        sh.nrw = 0;
+      }
+      __syncthreads();
+      int my_rw = 0, my_chk = 0;
+      for (int e = tid; e < nu; e += TPB) {
+        const double s_cost = ncost + sh.ud[e];
+        if (sh.ucost[e] > s_cost) {          // near_node.cost > s_cost :1241
+          my_chk++;
+          if (sh.ufree[e]) {                 // check_collision(near_node, theta, d) :1244
+            const int u = sh.uidx[e];
+            parent[u] = n;
+            cost[u] = s_cost;
+            my_rw++;
+          }
+        }
+      }
+      if (my_rw) atomicAdd(&sh.nrw, my_rw);
+      if (my_chk) atomicAdd(&sh.nvalid, my_chk);   // nvalid reused: rewire collision tests requested
+      n++;
+      __syncthreads();
+      s_rw += sh.nrw;
+      s_eu += sh.nvalid - nvalid;
+      s_er += sh.nvalid - nvalid;
+      // ---------------- goal bookkeeping :1094-1103
+      if (tid == 0) {
+        sh.flag = (rpp::py_hypot(nx - gx, ny - gy) < E) ? 1 : 0;   // is_near_goal :1226-1230 (strict)
+        sh.ecoll = 0;
+      }
+      __syncthreads();
+      if (sh.flag) {
+        s_eu++;
+        s_er++;
+        for (int k = tid; k < c.m; k += TPB)
+          if (seg_dist2(nx, ny, gx, gy, sh.ox[k], sh.oy[k]) <= sh.othr[k]) sh.ecoll = 1;   // check_segment_collision :1095
+        __syncthreads();
+        if (!sh.ecoll && tid == 0) {
+          // get_final_course :1278-1285 + get_path_len :1193-1203 (walk first for the length, store if it improves)
+          double len = 0.0, px = gx, py = gy;
+          int li = n - 1, np = 1;
+          while (parent[li] >= 0) {
+            const double cx = x[li], cy = y[li];
+            len += rpp::py_hypot(cx - px, cy - py);
+            px = cx;
+            py = cy;
+            li = parent[li];
+            np++;
+          }
+          len += rpp::py_hypot(sx0 - px, sy0 - py);
+          np++;
+          if (len < sh.cbest) {
+            sh.cbest = len;
+            int trunc = 0, k = 0;
+            pathbuf[0] = gx;
+            pathbuf[1] = gy;
+            k = 1;
+            li = n - 1;
+            while (parent[li] >= 0) {
+              if (k < c.path_cap) {
+                pathbuf[2 * k] = x[li];
+                pathbuf[2 * k + 1] = y[li];
+              } else {
+                trunc = 1;
+              }
+              k++;
+              li = parent[li];
+            }
+            if (k < c.path_cap) {
+              pathbuf[2 * k] = sx0;
+              pathbuf[2 * k + 1] = sy0;
+            } else {
+              trunc = 1;
+            }
+            k++;
+            I->path_n = k;
+            I->goal_node = n - 1;
+            I->status = (I->status & ~8) | 2 | (trunc ? 8 : 0);
+            c.results[inst].path_cost = len;
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (inst == c.trace_inst && tid == 0) {
+      c.tr_rx[it] = rx;
+      c.tr_ry[it] = ry;
+      c.tr_near[it] = ni;
+      c.tr_nn[it] = nnear;
+    }
+    if (sh.overflow) stop = 1;
+    __syncthreads();
+  }
+
+  __syncthreads();
+  for (int i = tid; i < 624; i += TPB) I->rng.mt[i] = sh.rng.mt[i];
+  if (tid == 0) {
+    I->rng.pos = sh.rng.pos;
+    I->sobol = sob;
+    I->n = n;
+    I->it = it;
+    cbest_io[inst] = sh.cbest;
+    if (it >= c.max_iter || sh.overflow) I->status |= 1;
+    if (sh.overflow) I->status |= 4;
+    I->iterations += s_iter;
+    I->edges_unique += s_eu;
+    I->edges_ref += s_er;
+    I->near_hits += s_nh;
+    I->near_unique += s_nu;
+    I->rewires += s_rw;
+    I->scan_nodes += s_sn;
+    I->alg_bytes += s_ab;
+    I->alg_bytes2 += s_ab;
+    I->exact_rescans += s_ex;
+    c.results[inst].n_nodes = n;
+    c.results[inst].status = I->status;
+  }
+}
+
+}  // namespace rppi

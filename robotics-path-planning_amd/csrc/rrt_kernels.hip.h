@@ -123,7 +123,8 @@ __device__ __forceinline__ v2d stream2(const double* p) {
 // ---------------------------------------------------------------------------
 // block-wide (value, index) argmin with lowest-index tie break; `second` is the
 // smallest value held by any element other than the winner (for the filter).
-__device__ __forceinline__ void block_argmin(double best, int bidx, double second, Sh& sh, double& gbest, int& gidx,
+template <class SH>
+__device__ __forceinline__ void block_argmin(double best, int bidx, double second, SH& sh, double& gbest, int& gidx,
                                              double& gsecond) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   double b = best;
@@ -174,8 +175,9 @@ __device__ __forceinline__ void block_argmin(double best, int bidx, double secon
 // Streaming argmin of dx*dx+dy*dy over x[0..n), y[0..n): each wave streams one
 // contiguous quarter with 16-byte loads (lane -> 2 adjacent nodes), UNROLL
 // independent load pairs in flight per lane.  Arrays are +inf padded.
+template <class SH>
 __device__ __forceinline__ void scan_nearest(const double* __restrict__ x, const double* __restrict__ y, int n,
-                                             double qx, double qy, Sh& sh, int& ni, double& gbest, double& gsecond) {
+                                             double qx, double qy, SH& sh, int& ni, double& gbest, double& gsecond) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
   const int ws = w * per;
@@ -219,8 +221,9 @@ __device__ __forceinline__ void scan_nearest(const double* __restrict__ x, const
 // ascending order, to hits[] (wave w owns the slots starting at its range start;
 // in-wave order by ballot prefix).  Returns the total; sh.wave_cnt/wave_start
 // describe the four segments.
+template <class SH>
 __device__ __forceinline__ int scan_hits(const double* __restrict__ x, const double* __restrict__ y, int n, double qx,
-                                         double qy, double thr, int32_t* __restrict__ hits, Sh& sh) {
+                                         double qy, double thr, int32_t* __restrict__ hits, SH& sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
   const int ws = w * per;
@@ -333,7 +336,8 @@ __device__ __forceinline__ int scan_fused(const double* __restrict__ x, const do
 }
 
 // h-th hit of the (virtual) concatenated, ascending list
-__device__ __forceinline__ int hit_at(const int32_t* hits, const Sh& sh, int h) {
+template <class SH>
+__device__ __forceinline__ int hit_at(const int32_t* hits, const SH& sh, int h) {
   int k = 0;
 #pragma unroll
   for (int j = 0; j < NW - 1; j++) {

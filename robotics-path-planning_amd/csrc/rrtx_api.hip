@@ -15,6 +15,7 @@
 #include "../../include/rrtx.h"
 #include "rrt_kernels.hip.h"
 #include "rrt_star_v2.hip.h"
+#include "rrt_informed.hip.h"
 
 using rppk::Ctx;
 using rppk::Inst;
@@ -53,6 +54,7 @@ struct rrtx_handle {
   std::string err;
   std::vector<void*> allocs;
   int chunk_iters = 1024;
+  double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
 };
 
 #define HIPCHK(h, expr)                                                                      \
@@ -103,7 +105,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if (!p || !out) return RRTX_E_INVALID;
   *out = nullptr;
   if (p->abi_version != RRTX_ABI_VERSION) return RRTX_E_INVALID;
-  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR) return RRTX_E_INVALID;
+  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED) return RRTX_E_INVALID;
   if (p->n_instances < 1 || p->max_iter < 0 || !(p->path_resolution > 0.0) || !(p->expand_dis >= 0.0))
     return RRTX_E_INVALID;
   int ndev = 0;
@@ -170,9 +172,17 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   // exactly the expression the reference evaluates per iteration; it depends on nnode only.
   std::vector<double> r2((size_t)cap + 2, 0.0);
   for (int64_t nn = 1; nn < cap + 2; nn++) {
-    double r = p->connect_circle_dist * libm_sqrt(libm_log((double)nn) / (double)nn);
-    if (p->expand_dis < r) r = p->expand_dis;
+    double r;
+    if (p->algo == RRTX_ALGO_INFORMED) {
+      r = 50.0 * libm_sqrt(libm_log((double)nn) / (double)nn);   // rrt_07:1139, indexed by len(node_list), no cap
+    } else {
+      r = p->connect_circle_dist * libm_sqrt(libm_log((double)nn) / (double)nn);
+      if (p->expand_dis < r) r = p->expand_dis;
+    }
     r2[nn] = py_sq_host(r);
+  }
+  if (p->algo == RRTX_ALGO_INFORMED) {
+    if ((rc = dalloc(h, &h->cbest, h->n_inst))) return rc;
   }
   HIPCHK(h, hipMemcpy(dr2, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
   // default per-instance state: ctor start/goal, RNG seeded with the instance number
@@ -307,9 +317,22 @@ int rrtx_plan(rrtx_handle* h) {
       launches++;
     }
   }
+  if (c.algo == RRTX_ALGO_INFORMED) {
+    std::vector<double> inf(B, INFINITY);
+    HIPCHK(h, hipMemcpy(h->cbest, inf.data(), sizeof(double) * B, hipMemcpyHostToDevice));
+  }
+  rppi::InformedArgs ia;
+  for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
+  ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
+  ia.xc[1] = (h->p.start[1] + h->p.goal[1]) / 2.0;
+  ia.c_min2 = py_sq_host(h->p.informed_c_min);       // c_min ** 2 rrt_07:1147
   for (;;) {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);
+    if (c.algo == RRTX_ALGO_INFORMED)
+      hipLaunchKernelGGL(rppi::rrt_informed_kernel, dim3(B), dim3(rppi::TPB), 0, h->stream, c, ia, h->cbest,
+                         h->chunk_iters);
+    else
+      hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));

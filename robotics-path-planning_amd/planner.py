@@ -239,6 +239,88 @@ class RRTStar(_PlannerBase):
     plan = planning
 
 
+class InformedNode:
+    """rrt_07's top-level Node (:1020-1025): integer parent index, no path arrays."""
+
+    def __init__(self, x, y):
+        self.x = x
+        self.y = y
+        self.cost = 0.0
+        self.parent = None
+
+
+def informed_rotation(start_xy, goal_xy):
+    """c_min and the rotation-to-world matrix `c`, computed with numpy exactly as rrt_07:1054-1068 does."""
+    c_min = math.hypot(start_xy[0] - goal_xy[0], start_xy[1] - goal_xy[1])
+    a1 = np.array([[(goal_xy[0] - start_xy[0]) / c_min], [(goal_xy[1] - start_xy[1]) / c_min], [0]])
+    id1_t = np.array([1.0, 0.0, 0.0]).reshape(1, 3)
+    m = a1 @ id1_t
+    u, s, vh = np.linalg.svd(m, True, True)
+    c = u @ np.diag([1.0, 1.0, np.linalg.det(u) * np.linalg.det(np.transpose(vh))]) @ vh
+    return c_min, c
+
+
+class InformedRRTStar:
+    """Drop-in for rrt_07's `RRT` (10_path_planning_01_rrt_07_informed_rrt_star.py:1027-1285)."""
+
+    def __init__(self, start, goal, obstacle_list, rand_area, expand_dis=0.5, goal_sample_rate=10, max_iter=200,
+                 sobol_sampler=False, device=0):
+        self.start = InformedNode(start[0], start[1])
+        self.goal = InformedNode(goal[0], goal[1])
+        self.min_rand = rand_area[0]
+        self.max_rand = rand_area[1]
+        self.expand_dis = expand_dis
+        self.goal_sample_rate = goal_sample_rate
+        self.max_iter = max_iter
+        self.obstacle_list = obstacle_list
+        self.node_list = None
+        self.sobol_sampler = sobol_sampler
+        self.sobol_inter_ = 0
+        self.device = device
+        self.stats = None
+        self._trace = False
+        self.trace = None
+
+    def informed_rrt_star_search(self, animation=True):
+        c_min, c = informed_rotation([self.start.x, self.start.y], [self.goal.x, self.goal.y])
+        h = _abi.Handle(_abi.ALGO_INFORMED, [self.start.x, self.start.y], [self.goal.x, self.goal.y],
+                        [self.min_rand, self.max_rand], self.expand_dis, 1.0, self.goal_sample_rate, self.max_iter,
+                        sampler=_abi.SAMPLER_SOBOL if self.sobol_sampler else _abi.SAMPLER_MT, n_instances=1,
+                        device=self.device, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+        try:
+            h.set_obstacles(self.obstacle_list)
+            st = random.getstate()
+            h.set_rng_state(0, st)
+            if self._trace:
+                h.enable_trace(0)
+            h.plan()
+            random.setstate(h.get_rng_state(0, st[2]))
+            x, y, cost, parent = h.get_tree(0)
+            nodes = []
+            for i in range(len(x)):
+                nd = InformedNode(float(x[i]), float(y[i]))
+                nd.cost = float(cost[i])
+                nd.parent = None if parent[i] < 0 else int(parent[i])
+                nodes.append(nd)
+            self.node_list = nodes
+            self.tree = (x, y, cost, parent)
+            path = h.get_path(0)
+            self.stats = h.get_stats()
+            if self._trace:
+                self.trace = h.get_trace()
+            if self.sobol_sampler:
+                self.sobol_inter_ = h.get_sobol_index(0)
+        finally:
+            h.close()
+        return None if path is None else [[float(px), float(py)] for px, py in path]
+
+    plan = informed_rrt_star_search
+
+    @staticmethod
+    def get_path_len(path):
+        return get_path_length(path)
+
+
 def get_path_length(path):
     """rrt_04:1391-1399."""
     le = 0

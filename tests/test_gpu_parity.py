@@ -169,3 +169,57 @@ def test_host_classes_drop_in(gpu):
                      robot_radius=0.6)
     p1 = r1.planning(animation=False)
     assert len(r1.node_list) == 170 and len(p1) == 28 and np.array_equal(np.array(p1), g1["path"])
+
+
+@pytest.mark.parametrize("path", util.golden_files("rrt07"), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_informed_matches_reference_golden(gpu, path):
+    """rrt_07 Informed RRT* on the GPU vs the reference goldens (ints exact; doubles compared bit-exact, which holds
+    on this image because the numpy dot forms are restated as measured -- contract tolerance for floats is 1e-6)."""
+    g = util.load_golden(path)
+    kw = util.informed_kwargs_from_golden(g)
+    out = util.run_gpu_informed(kw, [int(g["seed"])], trace_instance=0)
+    d = util.first_trace_divergence(out["trace"], g["tr_rnd_x"], g["tr_rnd_y"], g["tr_nearest"])
+    assert d is None, "first divergent iteration %d" % d
+    x, y, cost, parent = out["trees"][0]
+    assert len(x) == len(g["x"]) and np.array_equal(parent, g["parent"])
+    assert np.allclose(x, g["x"], rtol=0, atol=1e-6) and np.allclose(cost, g["cost"], rtol=0, atol=1e-6)
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    p = out["paths"][0]
+    if len(g["path"]) == 0:
+        assert p is None
+    else:
+        assert p is not None and np.array_equal(p, g["path"])
+        assert out["results"][0][0] == float(g["path_len"])
+    st = out["rng"][0]
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
+def test_gpu_informed_batch_equals_oracle(gpu):
+    import oracle
+    g = util.load_golden(util.GOLDEN + "/rrt07_c3_sobol_s1_it3000.npz")
+    kw = util.informed_kwargs_from_golden(g)
+    kw["max_iter"] = 1500
+    seeds = list(range(1, 13))
+    out = util.run_gpu_informed(kw, seeds)
+    for i, s in enumerate(seeds):
+        r = oracle.plan_informed(seed=s, **kw)
+        util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % s)
+        assert (out["paths"][i] is None) == (r["path"] is None)
+        if r["path"] is not None:
+            assert np.array_equal(out["paths"][i], r["path"]) and out["results"][0][i] == r["c_best"]
+
+
+def test_informed_host_class_drop_in(gpu):
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt07_drv_mt_s42_it2000.npz")
+    kw = util.informed_kwargs_from_golden(g)
+    random.seed(42)
+    rrt = rrt_amd.InformedRRTStar(start=kw["start"], goal=kw["goal"], obstacle_list=kw["obstacles"],
+                                  rand_area=kw["rand_area"], expand_dis=0.5, goal_sample_rate=10, max_iter=2000,
+                                  sobol_sampler=False)
+    path = rrt.informed_rrt_star_search(animation=False)
+    assert len(rrt.node_list) == 1397 and len(path) == 13
+    assert rrt.get_path_len(path) == 17.33495114327498            # SURVEY.md section 10
+    assert rrt.node_list[5].parent == int(g["parent"][5]) and rrt.node_list[0].parent is None
+    assert random.getstate()[1][624] == int(g["rng_pos_after"])

@@ -42,3 +42,30 @@ def test_spot_values_survey_section10():
     import math
     le = sum(math.hypot(p[i + 1][0] - p[i][0], p[i + 1][1] - p[i][1]) for i in range(len(p) - 1))
     assert abs(le - 144.382254) < 1e-6
+
+
+@pytest.mark.parametrize("path", util.golden_files("rrt07"), ids=lambda p: p.split("/")[-1][:-4])
+def test_informed_oracle_matches_reference_golden(path):
+    """rrt_07 Informed RRT*: tree, best path, c_best, RNG state and per-iteration samples (incl. the ellipsoidal
+    informed samples, i.e. the numpy dot forms) equal the reference's, bit for bit."""
+    import oracle
+    g = util.load_golden(path)
+    kw = util.informed_kwargs_from_golden(g)
+    assert np.array_equal(oracle.rotation_to_world(kw["start"], kw["goal"]), g["rot_c"])
+    r = oracle.plan_informed(seed=int(g["seed"]), trace=True, **kw)
+    util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    if len(g["path"]) == 0:
+        assert r["path"] is None and r["c_best"] == float("inf")
+    else:
+        assert np.array_equal(r["path"], g["path"]) and r["c_best"] == float(g["path_len"])
+    assert r["rng"].pos == int(g["rng_pos_after"]) and r["rng"].mt[0] == int(g["rng_word0_after"])
+    n = len(g["tr_nearest"])
+    assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"])
+    assert np.array_equal(r["tr_rnd_x"][:n], g["tr_rnd_x"]) and np.array_equal(r["tr_rnd_y"][:n], g["tr_rnd_y"])
+    if kw["sobol"]:
+        assert r["stats"]["sobol_index"] == int(g["sobol_index_after"])
+
+
+def test_informed_spot_value_survey_section10():
+    g = util.load_golden(util.GOLDEN + "/rrt07_drv_mt_s42_it2000.npz")
+    assert len(g["x"]) == 1397 and len(g["path"]) == 13 and float(g["path_len"]) == 17.33495114327498

@@ -10,7 +10,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def golden_files(prefix=""):
-    return sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+    """rrt_01 / rrt_04 goldens by default; prefix="rrt07" selects the Informed RRT* ones."""
+    fs = sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
+    if not prefix:
+        fs = [f for f in fs if not os.path.basename(f).startswith("rrt07")]
+    return fs
 
 
 def load_golden(path):
@@ -109,3 +113,39 @@ def assert_tree_equal(got, want, what=""):
     assert np.array_equal(gx, wx) and np.array_equal(gy, wy), "%s: coordinates differ" % what
     if wc is not None:
         assert np.array_equal(gc, wc), "%s: cost[] differs (max abs %g)" % (what, float(np.abs(gc - wc).max()))
+
+
+def informed_kwargs_from_golden(g):
+    return dict(start=[float(v) for v in g["start"]], goal=[float(v) for v in g["goal"]],
+                obstacles=[tuple(float(v) for v in o) for o in g["obstacles"]],
+                rand_area=[float(v) for v in g["rand_area"]], expand_dis=float(g["expand_dis"]),
+                goal_sample_rate=int(g["goal_sample_rate"]), max_iter=int(g["max_iter"]), sobol=int(g["sobol"]))
+
+
+def run_gpu_informed(kw, seeds, device=0, trace_instance=None):
+    """Informed RRT* (rrt_07) instances on the GPU through the C ABI."""
+    import rrt_amd
+    A = rrt_amd._abi
+    c_min, c = rrt_amd.informed_rotation(kw["start"], kw["goal"])
+    h = A.Handle(A.ALGO_INFORMED, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], 1.0,
+                 kw["goal_sample_rate"], kw["max_iter"], sampler=A.SAMPLER_SOBOL if kw["sobol"] else A.SAMPLER_MT,
+                 n_instances=len(seeds), device=device, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]],
+                 informed_c_min=c_min)
+    try:
+        h.set_obstacles(kw["obstacles"])
+        h.seed_instances(seeds)
+        if trace_instance is not None:
+            h.enable_trace(trace_instance)
+        h.plan()
+        out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], paths=[], rng=[])
+        for i in range(len(seeds)):
+            out["trees"].append(h.get_tree(i))
+            out["paths"].append(h.get_path(i))
+            out["rng"].append(h.get_rng_state(i))
+        if trace_instance is not None:
+            out["trace"] = h.get_trace()
+        if kw["sobol"]:
+            out["sobol_index"] = [h.get_sobol_index(i) for i in range(len(seeds))]
+    finally:
+        h.close()
+    return out
