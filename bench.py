@@ -57,7 +57,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
-    if a.gpus > 1 or world > 1:
+    if a.gpus > 1 or world > 1 or os.environ.get("RRTX_BENCH_FORCE_DIST"):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
