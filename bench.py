@@ -38,7 +38,10 @@ def main():
     ap.add_argument("--instances", type=int, default=int(os.environ.get("RRTX_BENCH_INSTANCES", "2048")),
                     help="planning instances per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
-    ap.add_argument("--obstacles", type=int, default=50)
+    ap.add_argument("--obstacles", type=int, default=None)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations (the headline metric); c3: rrt_07 Informed RRT* "
+                         "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 1024 instances")
     ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
@@ -51,6 +54,14 @@ def main():
 
     import numpy as np
     import util
+    c3 = a.workload == "c3"
+    if a.obstacles is None:
+        a.obstacles = 200 if c3 else 50
+    if c3:
+        if "--max-iter" not in sys.argv:
+            a.max_iter = 20000
+        if "--instances" not in sys.argv:
+            a.instances = 768
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,15 +81,25 @@ def main():
     sharding = importlib.import_module("robotics-path-planning_amd.sharding")
     A = rrt_amd._abi
     kw = util.c2_kwargs(a.max_iter, m=a.obstacles)
+    if c3:
+        kw = dict(algo="informed", start=[2, 2], goal=[98, 98], obstacles=util.synth_map(11, a.obstacles, 0.3, 1.5),
+                  rand_area=[0, 100], expand_dis=0.5, goal_sample_rate=10, max_iter=a.max_iter, sobol=1)
     B = a.instances
     seeds = sharding.shard_seeds(rank, B)          # rank r owns seeds r*B+1 .. (r+1)*B, no exchange while planning
     cuda = torch.device("cuda", local_rank) if dist is not None else None
 
     def make_handle(max_iter):
-        h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
-                     kw["goal_sample_rate"], max_iter, play_area=None, robot_radius=kw["robot_radius"],
-                     sampler=A.SAMPLER_MT, connect_circle_dist=kw["connect_circle_dist"], search_until_max_iter=True,
-                     n_instances=B, device=device)
+        if c3:
+            c_min, c = rrt_amd.informed_rotation(kw["start"], kw["goal"])
+            h = A.Handle(A.ALGO_INFORMED, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], 1.0,
+                         kw["goal_sample_rate"], max_iter, sampler=A.SAMPLER_SOBOL, n_instances=B, device=device,
+                         informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+        else:
+            h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"],
+                         kw["path_resolution"], kw["goal_sample_rate"], max_iter, play_area=None,
+                         robot_radius=kw["robot_radius"], sampler=A.SAMPLER_MT,
+                         connect_circle_dist=kw["connect_circle_dist"], search_until_max_iter=True, n_instances=B,
+                         device=device)
         h.set_obstacles(kw["obstacles"])
         h.seed_instances(seeds)
         return h
@@ -150,13 +171,16 @@ def main():
         except Exception:  # noqa: BLE001
             pass
         line = {
-            "metric": "RRT* collision-checked edge expansions/sec (unique edges evaluated on device), "
-                      "%d-iteration trees" % a.max_iter,
+            "metric": "%s collision-checked edge expansions/sec (unique edges evaluated on device), "
+                      "%d-iteration trees" % ("Informed RRT*" if c3 else "RRT*", a.max_iter),
             "value": value, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": steps_done, "warmup": a.warmup,
             "ms_per_step": 1e3 * tmax / max(steps_done, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "C2: rrt_04 RRT*, %d circle obstacles (map_seed 7) on 100x100, expand_dis 2.0, "
-                                   "path_resolution 0.25, max_iter %d, %d instances/GPU (seeds 1..), MT sampler"
+            "config": {"workload": ("C3: rrt_07 Informed RRT*, Sobol sampler, %d circle obstacles (map_seed 11, radii "
+                                    "U(0.3,1.5)) on 100x100, expand_dis 0.5, max_iter %d, %d instances/GPU (seeds 1..)"
+                                    if c3 else
+                                    "C2: rrt_04 RRT*, %d circle obstacles (map_seed 7) on 100x100, expand_dis 2.0, "
+                                    "path_resolution 0.25, max_iter %d, %d instances/GPU (seeds 1..), MT sampler")
                                    % (a.obstacles, a.max_iter, B),
                        "instances_per_gpu": B, "max_iter": a.max_iter, "parallelism": "instances x%d" % ngpu},
             "edge_expansions_reference_equivalent_per_s": tot_edges_r / tmax,
@@ -167,7 +191,8 @@ def main():
             "iterations_per_s": iters * ngpu / tmax,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "rppk::rrt_plan_kernel", "launches": launches,
+                         "kernel": "rppi::rrt_informed_kernel" if c3 else "rppk2(s)::rrt_star_kernel_v2",
+                         "launches": launches,
                          "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
                          "traffic_note": traffic_note,
                          "survey_8d_two_scan_GBps": achieved_2s, "survey_8d_two_scan_frac": achieved_2s / 8000.0,
@@ -179,16 +204,22 @@ def main():
         }
         if not a.no_cpu_baseline:
             import oracle
-            kc = util.c2_kwargs(a.cpu_iters, m=a.obstacles)
             tc = time.perf_counter()
-            r = oracle.plan(seed=1, exact_pow=False, **kc)
+            if c3:
+                kc = dict(kw)
+                kc.pop("algo")
+                kc["max_iter"] = min(a.cpu_iters, a.max_iter)
+                r = oracle.plan_informed(seed=1, exact_pow=False, **kc)
+            else:
+                kc = util.c2_kwargs(a.cpu_iters, m=a.obstacles)
+                r = oracle.plan(seed=1, exact_pow=False, **kc)
             tc = time.perf_counter() - tc
             line["cpu_baseline"] = {"value": r["stats"]["edges_unique"] / tc, "unit": "edge expansions/s", "cores": 1,
                                     "kind": "port",
                                     "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference), 1 instance, "
-                                              "seed 1, %d iterations (%d nodes) of the same C2 workload, %.1f s; "
+                                              "seed 1, %d iterations (%d nodes) of the same workload, %.1f s; "
                                               "reference-equivalent rate %.0f/s"
-                                              % (a.cpu_iters, len(r["x"]), tc, r["stats"]["edges_ref"] / tc)}
+                                              % (kc["max_iter"], len(r["x"]), tc, r["stats"]["edges_ref"] / tc)}
         print(json.dumps(line), flush=True)
     h.close()
     if dist is not None:
