@@ -71,6 +71,8 @@ def run_rrt04(mod, name, obstacles, start, goal, rand_area, expand_dis, path_res
               play_area=play_area, robot_radius=robot_radius)
     if algo == "rrt_star":
         kw.update(sobol_sampler=sobol, connect_circle_dist=ccd, search_until_max_iter=until_max)
+    if algo == "rrt" and sobol:
+        pass  # rrt_02: the class itself always draws Sobol points
     rrt = mod.RRT(**kw)
     tr = {"rnd_x": [], "rnd_y": [], "nearest": [], "n_near": [], "n_nodes": []}
     edges = [0]
@@ -270,3 +272,12 @@ def main07(only=""):
     for n, kw in jobs:
         if n.startswith(only):
             run_rrt07(m07, n, **kw)
+
+
+def main02():
+    """rrt_02 (plain RRT + Sobol sampler) driver scenario, rrt_02:1290-1330 constants = rrt_01's."""
+    m02 = ref_loader.load("rrt_02")
+    drv = dict(obstacles=DRIVER_OBST, start=[0, 0], goal=[6.0, 10.0], rand_area=[-2, 15], expand_dis=1.0,
+               path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.6, ccd=50.0)
+    for seed in (0, 1, 2, 3, 42):
+        run_rrt04(m02, "rrt02_drv_s%d" % seed, sobol=1, until_max=False, seed=seed, algo="rrt", **drv)

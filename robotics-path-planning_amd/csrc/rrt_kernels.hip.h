@@ -727,7 +727,7 @@ template <class SH>
 __device__ __forceinline__ void draw_sample(const Ctx& c, SH& sh, rpp::Sobol& sob, double gx, double gy) {
   double rx, ry;
   if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {
-    if (c.sampler == 1 && c.algo == 1) {
+    if (c.sampler == 1) {   // rrt_04:1142-1153, rrt_02:1077-1089
       double q[2];
       rpp::sobol_next(&sob, q);
       rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);

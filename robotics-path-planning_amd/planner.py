@@ -214,6 +214,23 @@ class RRT(_PlannerBase):
     plan = planning
 
 
+class RRTSobol(RRT):
+    """Drop-in for rrt_02's `RRT` (10_path_planning_01_rrt_02_sobol_sampler.py:932-1089): rrt_01 whose
+    get_random_node draws the 2-D Sobol sequence (:1077-1089)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.sobol_inter_ = 0
+
+    def planning(self, animation=True):
+        path = self._run(_abi.SAMPLER_SOBOL, 50.0, False)
+        if animation:  # pragma: no cover
+            self.draw_graph()
+        return path
+
+    plan = planning
+
+
 class RRTStar(_PlannerBase):
     """Drop-in for rrt_04's `RRT` (10_path_planning_01_rrt_04_rrt_star.py:932-1384)."""
     _ALGO = _abi.ALGO_RRT_STAR
