@@ -281,3 +281,90 @@ def main02():
                path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.6, ccd=50.0)
     for seed in (0, 1, 2, 3, 42):
         run_rrt04(m02, "rrt02_drv_s%d" % seed, sobol=1, until_max=False, seed=seed, algo="rrt", **drv)
+
+
+# ------------------------------------------------------------------------------------------------ rrt_05
+def run_rrt05(mod, name, obstacles, start, goal, rand_area, max_iter, seed, curvature=1.0, robot_radius=0.0,
+              goal_sample_rate=10, expand_dis=3.0, ccd=50.0):
+    """RRT*-Dubins (rrt_05:1335-1795), driver-style call planning(animation=False)."""
+    random.seed(seed)
+    rrt = mod.RRT(start=start, goal=goal, obstacle_list=obstacles, rand_area=rand_area, expand_dis=expand_dis,
+                  path_resolution=0.5, goal_sample_rate=goal_sample_rate, max_iter=max_iter, play_area=None,
+                  robot_radius=robot_radius, sobol_sampler=True, connect_circle_dist=ccd, search_until_max_iter=True,
+                  curvature=curvature, goal_yaw_th=np.deg2rad(1.0), goal_xy_th=0.5)
+    tr = {"rx": [], "ry": [], "ryaw": [], "nearest": [], "n_near": []}
+    o_near = mod.RRT.get_nearest_node_index
+    o_fn = rrt.find_near_nodes
+
+    def near_hook(node_list, rnd):
+        i = o_near(node_list, rnd)
+        tr["rx"].append(float(rnd.x)); tr["ry"].append(float(rnd.y)); tr["ryaw"].append(float(rnd.yaw))
+        tr["nearest"].append(i)
+        return i
+
+    def fn_hook(new_node):
+        r = o_fn(new_node)
+        tr["n_near"].append(len(r))
+        return r
+    rrt.get_nearest_node_index = near_hook
+    rrt.find_near_nodes = fn_hook
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = rrt.planning(animation=False)
+    dt = time.time() - t0
+    nl = rrt.node_list
+    x, y, cost, parent = tree_arrays(nl)
+    yaw = np.array([float(nd.yaw) for nd in nl])
+    plen = np.array([len(nd.path_x) for nd in nl], dtype=np.int32)
+    ppx = np.concatenate([np.asarray(nd.path_x, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
+    ppy = np.concatenate([np.asarray(nd.path_y, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
+    state = random.getstate()
+    out = dict(algo="rrt_star_dubins", seed=seed, obstacles=np.array(obstacles, dtype=np.float64),
+               start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
+               rand_area=np.array(rand_area, dtype=np.float64), max_iter=max_iter, curvature=curvature,
+               robot_radius=robot_radius, goal_sample_rate=goal_sample_rate, expand_dis=expand_dis,
+               connect_circle_dist=ccd, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5,
+               x=x, y=y, yaw=yaw, cost=cost, parent=parent, poly_len=plen, poly_x=ppx, poly_y=ppy,
+               path=np.array(path if path is not None else [], dtype=np.float64).reshape(-1, 2),
+               path_found=int(path is not None), ref_seconds=dt,
+               rng_pos_after=state[1][624], rng_word0_after=np.uint32(state[1][0]),
+               tr_rx=np.array(tr["rx"]), tr_ry=np.array(tr["ry"]), tr_ryaw=np.array(tr["ryaw"]),
+               tr_nearest=np.array(tr["nearest"], dtype=np.int32), tr_n_near=np.array(tr["n_near"], dtype=np.int32))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-28s nodes=%d path=%s maxcost=%r  %.2fs" % (name, len(x), None if path is None else len(path),
+                                                        float(cost.max()), dt), flush=True)
+
+
+def main05(only=""):
+    m05 = ref_loader.load("rrt_05")
+    obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)]       # rrt_05:1804-1806
+    drv = dict(obstacles=obst, start=[0.0, 0.0, float(np.deg2rad(0.0))], goal=[10.0, 10.0, float(np.deg2rad(0.0))],
+               rand_area=[-2, 15])
+    for seed, it in ((42, 150), (42, 500), (1, 300), (2, 300), (7, 400)):
+        n = "rrt05_drv_s%d_it%d" % (seed, it)
+        if n.startswith(only):
+            run_rrt05(m05, n, max_iter=it, seed=seed, **drv)
+    # Dubins primitive known-answer vectors: plan_dubins_path on random poses (no planner around it)
+    rng = random.Random(5)
+    rows = []
+    for k in range(400):
+        sx, sy, syaw = rng.uniform(-2, 15), rng.uniform(-2, 15), rng.uniform(-math_pi(), math_pi())
+        gx, gy, gyaw = rng.uniform(-2, 15), rng.uniform(-2, 15), rng.uniform(-math_pi(), math_pi())
+        if k % 7 == 0:
+            gx, gy = sx + rng.uniform(-0.3, 0.3), sy + rng.uniform(-0.3, 0.3)
+        px, py, pyaw, mode, lengths = m05.plan_dubins_path(sx, sy, syaw, gx, gy, gyaw, 1.0)
+        rows.append(dict(inp=[sx, sy, syaw, gx, gy, gyaw], n=len(px), end=[float(px[-1]), float(py[-1]), float(pyaw[-1])],
+                         lengths=[float(v) for v in lengths], mode="".join(mode),
+                         chk=[float(np.sum(px)), float(np.sum(py))], px=np.asarray(px, dtype=np.float64),
+                         py=np.asarray(py, dtype=np.float64)))
+    np.savez_compressed(os.path.join(OUT, "dubins_kat.npz"),
+                        inp=np.array([r["inp"] for r in rows]), n=np.array([r["n"] for r in rows], dtype=np.int32),
+                        end=np.array([r["end"] for r in rows]), lengths=np.array([r["lengths"] for r in rows]),
+                        mode=np.array([r["mode"] for r in rows]),
+                        poly_x=np.concatenate([r["px"] for r in rows]), poly_y=np.concatenate([r["py"] for r in rows]))
+    print("dubins_kat: 400 cases", flush=True)
+
+
+def math_pi():
+    import math
+    return math.pi

@@ -180,3 +180,80 @@ def plan_informed(start, goal, obstacles, rand_area, expand_dis=0.5, goal_sample
         t = o.tr_n
         res.update(tr_rnd_x=trx[:t].copy(), tr_rnd_y=try_[:t].copy(), tr_nearest=trn[:t].copy(), tr_n_near=trk[:t].copy())
     return res
+
+
+class DOut(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("yaw", C.c_void_p), ("cost", C.c_void_p), ("parent", C.c_void_p),
+                ("cap", C.c_int32), ("n", C.c_int32),
+                ("poly_len", C.c_void_p), ("poly_x", C.c_void_p), ("poly_y", C.c_void_p),
+                ("poly_cap", C.c_int64), ("poly_n", C.c_int64),
+                ("path_xy", C.c_void_p), ("path_cap", C.c_int32), ("path_n", C.c_int32),
+                ("tr_rx", C.c_void_p), ("tr_ry", C.c_void_p), ("tr_ryaw", C.c_void_p), ("tr_nearest", C.c_void_p),
+                ("tr_n_near", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32)]
+
+
+def dubins(sx, sy, syaw, gx, gy, gyaw, curvature=1.0, cap=4096):
+    """plan_dubins_path (rrt_05:1021-1109) on the oracle: (px, py, pyaw, mode, lengths)."""
+    L = lib()
+    L.orc_dubins.restype = C.c_int
+    L.orc_dubins.argtypes = [C.c_double] * 7 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p]
+    px = np.zeros(cap); py = np.zeros(cap); pyaw = np.zeros(cap); ln = np.zeros(3)
+    mode = C.create_string_buffer(4)
+    n = L.orc_dubins(sx, sy, syaw, gx, gy, gyaw, curvature, px.ctypes.data, py.ctypes.data, pyaw.ctypes.data, cap,
+                     ln.ctypes.data, mode)
+    return px[:n].copy(), py[:n].copy(), pyaw[:n].copy(), mode.value.decode(), ln
+
+
+def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=None, curvature=1.0, robot_radius=0.0,
+                goal_sample_rate=10, expand_dis=3.0, connect_circle_dist=50.0, goal_yaw_th=None, goal_xy_th=0.5,
+                trace=False):
+    """One RRT.planning(animation=False) call of rrt_05 (RRT*-Dubins) on the oracle."""
+    L = lib()
+    L.orc_plan_dubins.restype = C.c_int
+    L.orc_plan_dubins.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
+                                  C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    p = Params()
+    p.algo = 3
+    p.goal_sample_rate, p.max_iter = int(goal_sample_rate), int(max_iter)
+    p.start[0], p.start[1] = float(start[0]), float(start[1])
+    p.goal[0], p.goal[1] = float(goal[0]), float(goal[1])
+    p.rand_min, p.rand_max = float(rand_area[0]), float(rand_area[1])
+    p.expand_dis = float(expand_dis)
+    p.robot_radius = float(robot_radius)
+    p.connect_circle_dist = float(connect_circle_dist)
+    if goal_yaw_th is None:
+        goal_yaw_th = float(np.deg2rad(1.0))
+    obst = np.ascontiguousarray(np.array(obstacles, dtype=np.float64).reshape(-1, 3))
+    if rng is None:
+        rng = mt_from_seed(seed)
+    cap = int(max_iter) + 2
+    pcap = cap * 2048
+    x = np.zeros(cap); y = np.zeros(cap); yaw = np.zeros(cap); cost = np.zeros(cap); parent = np.zeros(cap, dtype=np.int32)
+    plen = np.zeros(cap, dtype=np.int32); ppx = np.zeros(pcap); ppy = np.zeros(pcap)
+    path = np.zeros((pcap, 2))
+    o = DOut()
+    o.x, o.y, o.yaw, o.cost, o.parent = x.ctypes.data, y.ctypes.data, yaw.ctypes.data, cost.ctypes.data, parent.ctypes.data
+    o.cap = cap
+    o.poly_len, o.poly_x, o.poly_y, o.poly_cap = plen.ctypes.data, ppx.ctypes.data, ppy.ctypes.data, pcap
+    o.path_xy, o.path_cap = path.ctypes.data, pcap
+    if trace:
+        trx = np.zeros(max_iter); try_ = np.zeros(max_iter); tryaw = np.zeros(max_iter)
+        trn = np.zeros(max_iter, dtype=np.int32); trk = np.zeros(max_iter, dtype=np.int32)
+        o.tr_rx, o.tr_ry, o.tr_ryaw, o.tr_nearest, o.tr_n_near = (trx.ctypes.data, try_.ctypes.data, tryaw.ctypes.data,
+                                                                  trn.ctypes.data, trk.ctypes.data)
+        o.tr_cap = int(max_iter)
+    st = Stats()
+    rc = L.orc_plan_dubins(C.byref(p), float(start[2]), float(goal[2]), float(curvature), float(goal_yaw_th),
+                           float(goal_xy_th), obst.ctypes.data, len(obst), C.byref(rng), C.byref(o), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("orc_plan_dubins failed: %d" % rc)
+    n = o.n
+    res = dict(x=x[:n].copy(), y=y[:n].copy(), yaw=yaw[:n].copy(), cost=cost[:n].copy(), parent=parent[:n].copy(),
+               poly_len=plen[:n].copy(), poly_x=ppx[:o.poly_n].copy(), poly_y=ppy[:o.poly_n].copy(),
+               path=path[:o.path_n].copy() if o.path_n else None,
+               stats={k: getattr(st, k) for k, _ in Stats._fields_}, rng=rng)
+    if trace:
+        t = o.tr_n
+        res.update(tr_rx=trx[:t].copy(), tr_ry=try_[:t].copy(), tr_ryaw=tryaw[:t].copy(), tr_nearest=trn[:t].copy(),
+                   tr_n_near=trk[:t].copy())
+    return res

@@ -69,3 +69,44 @@ def test_informed_oracle_matches_reference_golden(path):
 def test_informed_spot_value_survey_section10():
     g = util.load_golden(util.GOLDEN + "/rrt07_drv_mt_s42_it2000.npz")
     assert len(g["x"]) == 1397 and len(g["path"]) == 13 and float(g["path_len"]) == 17.33495114327498
+
+
+def test_dubins_known_answers():
+    """plan_dubins_path (rrt_05:1021-1109) on 400 random pose pairs: polyline, word, lengths and final yaw equal the
+    reference's bit for bit (pins the scipy rotation form, the numpy matmul forms and numpy's `%`)."""
+    import oracle
+    k = np.load(util.GOLDEN + "/dubins_kat.npz")
+    off = 0
+    for i in range(len(k["n"])):
+        n = int(k["n"][i])
+        px, py, pyaw, mode, ln = oracle.dubins(*k["inp"][i])
+        assert len(px) == n and mode == str(k["mode"][i])
+        assert np.array_equal(px, k["poly_x"][off:off + n]) and np.array_equal(py, k["poly_y"][off:off + n])
+        assert np.array_equal(ln, k["lengths"][i]) and pyaw[-1] == k["end"][i][2]
+        off += n
+    # SURVEY.md section 10 KAT: (1,1,45deg) -> (-3,-3,-45deg), curvature 1
+    import math
+    px, py, pyaw, mode, ln = oracle.dubins(1.0, 1.0, math.radians(45.0), -3.0, -3.0, math.radians(-45.0))
+    assert mode == "LSL" and len(px) == 94
+    assert list(ln) == [3.3531176436132273, 4.76301285963152, 1.3592713367714622]
+    assert (px[-1], py[-1], pyaw[-1]) == (-3.000000000000001, -2.9999999999999987, -0.7853981633974492)
+
+
+@pytest.mark.parametrize("path", util.golden_files("rrt05"), ids=lambda p: p.split("/")[-1][:-4])
+def test_dubins_rrt_star_oracle_matches_reference_golden(path):
+    """rrt_05 RRT*-Dubins: poses, costs, parents, every stored edge polyline, final course and RNG state."""
+    import oracle
+    g = util.load_golden(path)
+    r = oracle.plan_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]), seed=int(g["seed"]),
+                           trace=True)
+    util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(r["yaw"], g["yaw"])
+    assert np.array_equal(r["poly_len"], g["poly_len"]) and np.array_equal(r["poly_x"], g["poly_x"]) \
+        and np.array_equal(r["poly_y"], g["poly_y"])
+    if len(g["path"]) == 0:
+        assert r["path"] is None
+    else:
+        assert r["path"] is not None and np.array_equal(r["path"], g["path"])
+    assert r["rng"].pos == int(g["rng_pos_after"]) and r["rng"].mt[0] == int(g["rng_word0_after"])
+    n = len(g["tr_nearest"])
+    assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])

@@ -13,7 +13,7 @@ def golden_files(prefix=""):
     """rrt_01 / rrt_04 goldens by default; prefix="rrt07" selects the Informed RRT* ones."""
     fs = sorted(glob.glob(os.path.join(GOLDEN, prefix + "*.npz")))
     if not prefix:
-        fs = [f for f in fs if not os.path.basename(f).startswith("rrt07")]
+        fs = [f for f in fs if os.path.basename(f).startswith(("rrt01", "rrt02", "rrt04"))]
     return fs
 
 
