@@ -8,6 +8,7 @@
 #include <cmath>
 #include <dlfcn.h>
 #include "rpp_core.h"
+#include "rpp_dubins.h"
 
 static uint64_t s = 0x9E3779B97F4A7C15ULL;
 static inline uint64_t rnd() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
@@ -20,6 +21,7 @@ typedef void (*sob_fn)(int, double*);
 struct OMT { uint32_t mt[624]; int32_t pos; };
 typedef void (*seed_fn)(OMT*, uint64_t);
 typedef uint32_t (*next_fn)(OMT*);
+typedef int (*dub_fn)(double, double, double, double, double, double, double, double*, double*, double*, int, double*, char*);
 
 int main(int argc, char** argv) {
   if (argc < 3) { fprintf(stderr, "usage: %s liboracle.so N\n", argv[0]); return 2; }
@@ -33,6 +35,37 @@ int main(int argc, char** argv) {
   next_fn onext = (next_fn)dlsym(h, "orc_mt_next");
   long N = atol(argv[2]);
   long bad = 0;
+  dub_fn odub = (dub_fn)dlsym(h, "orc_dubins");
+  // fmod / numpy remainder
+  for (long i = 0; i < N * 5; i++) {
+    double a = (u01() * 2 - 1) * 40, b = 6.283185307179586;
+    if (i % 5 == 0) a *= 1e-3;
+    if (i % 7 == 0) b = (u01() * 2 - 1) * 3 + 1e-9;
+    if (i % 1009 == 0) a = 0.0;
+    double x = rpp::fmod_exact(a, b), y = fmod(a, b);
+    if (memcmp(&x, &y, 8)) { if (bad++ < 5) printf("fmod %a %a: %a vs %a\n", a, b, x, y); }
+  }
+  // Dubins: prepared plan + independent point evaluation == the oracle's sequential plan_dubins_path
+  {
+    static double opx[8192], opy[8192], opyaw[8192];
+    for (long i = 0; i < N / 100 + 50; i++) {
+      double sx = u01() * 17 - 2, sy = u01() * 17 - 2, syaw = (u01() * 2 - 1) * 3.141592653589793;
+      double gx = u01() * 17 - 2, gy = u01() * 17 - 2, gyaw = (u01() * 2 - 1) * 3.141592653589793;
+      if (i % 6 == 0) { gx = sx + (u01() - 0.5) * 0.5; gy = sy + (u01() - 0.5) * 0.5; }
+      if (i % 11 == 0) { gyaw = syaw; }
+      double ln[3]; char md[4];
+      int n = odub(sx, sy, syaw, gx, gy, gyaw, 1.0, opx, opy, opyaw, 8192, ln, md);
+      rpp::DubinsPlan P; rpp::dubins_prepare(&P, sx, sy, syaw, gx, gy, gyaw, 1.0);
+      if ((P.ok ? P.total : 0) != n) { if (bad++ < 5) printf("dubins count %d vs %d\n", P.total, n); continue; }
+      for (int k = 0; k < n; k++) {
+        double wx, wy, wyaw; rpp::dubins_point(P, k, 1.0, &wx, &wy, &wyaw);
+        if (memcmp(&wx, &opx[k], 8) || memcmp(&wy, &opy[k], 8) || memcmp(&wyaw, &opyaw[k], 8)) {
+          if (bad++ < 5) printf("dubins point %d/%d: (%a,%a,%a) vs (%a,%a,%a)\n", k, n, wx, wy, wyaw, opx[k], opy[k], opyaw[k]);
+          break;
+        }
+      }
+    }
+  }
   // hypot, **2
   for (long i = 0; i < N * 10; i++) {
     double a = (u01() * 2 - 1) * 120, b = (u01() * 2 - 1) * 120;

@@ -10,7 +10,8 @@ static inline uint64_t rnd(){ s^=s<<13; s^=s>>7; s^=s<<17; return s; }
 static inline double u01(){ return (rnd()>>11)*(1.0/9007199254740992.0); }
 int main(int argc,char**argv){
   long N = argc>1? atol(argv[1]):10000000;
-  long bad[4]={0,0,0,0}; int o;
+  long bad[5]={0,0,0,0,0}; int o;
+  double (*volatile pacos)(double)=acos;
   double (*volatile psin)(double)=sin; double (*volatile pcos)(double)=cos;
   double (*volatile patan2)(double,double)=atan2; double (*volatile ppow)(double,double)=pow;
   for(long i=0;i<N;i++){
@@ -27,7 +28,10 @@ int main(int argc,char**argv){
     double p=(u01()*2-1)*150; if(i%9==0) p*=1e-5; if(i%997==0) p=0;
     a=rpp_glibc_pow(p,2.0); b=ppow(p,2.0);
     if(memcmp(&a,&b,8)){ if(bad[3]++<5) printf("pow %a: %a vs %a\n",p,a,b);}
+    double ac=(u01()*2-1); if(i%17==0) ac*=1e-4; if(i%19==0) ac = ac>0? 1-ac*1e-6 : -1-ac*1e-6; if(i%997==1) ac=1; if(i%997==2) ac=-1;
+    a=rpp_glibc_acos(ac); b=pacos(ac);
+    if(memcmp(&a,&b,8)){ if(bad[4]++<5) printf("acos %a: %a vs %a\n",ac,a,b);}
   }
-  printf("N=%ld mismatches sin=%ld cos=%ld atan2=%ld pow=%ld\n",N,bad[0],bad[1],bad[2],bad[3]);
-  return (bad[0]||bad[1]||bad[2]||bad[3]);
+  printf("N=%ld mismatches sin=%ld cos=%ld atan2=%ld pow=%ld acos=%ld\n",N,bad[0],bad[1],bad[2],bad[3],bad[4]);
+  return (bad[0]||bad[1]||bad[2]||bad[3]||bad[4]);
 }

@@ -26,7 +26,7 @@ save/restore (MXCSR) is dropped: callers run in round-to-nearest.
 Branches that leave the restated domain (huge-argument reduction `__branred`,
 overflow/underflow error exits of pow) return NaN and raise the `ood` flag.
 
-Output: one header with `static inline double rpp_glibc_{sin,cos,atan2,pow}`.
+Output: one header with `static inline double rpp_glibc_{sin,cos,atan2,pow,acos}`.
 Verified against the live libm by tests/test_glibc_math.py.
 
 Usage: python tools/lift_libm.py [--libm PATH] [--out HEADER]
@@ -41,6 +41,7 @@ import sys
 FUNCS = [
     # name, entry, end(exclusive), args
     ("pow", 0x768b0, 0x76ee0, 2),
+    ("acos", 0x77960, 0x78060, 1),
     ("atan2", 0x78060, 0x789b0, 2),
     ("sin", 0x789b0, 0x791c0, 1),
     ("cos", 0x791c0, 0x799d0, 1),
@@ -712,7 +713,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libm", default="/lib/x86_64-linux-gnu/libm.so.6")
     ap.add_argument("--out", default="robotics-path-planning_amd/csrc/glibc235_fma_math.h")
-    ap.add_argument("--tables", default="aeb80:dc0,af960:870,b1b20:1048,be0e0:34b8",
+    ap.add_argument("--tables", default="aeb80:dc0,af960:870,b1b20:1048,b8bc0:e0,b8ca0:400,b90a0:5040,be0e0:34b8",
                     help="comma list base:size (hex) of lookup tables reached through lea; printed when omitted")
     a = ap.parse_args()
     L = Lifter(a.libm)
@@ -758,6 +759,7 @@ RPP_HD static inline double rpp_glibc_sin(double x) { int o = 0; return rpp_glib
 RPP_HD static inline double rpp_glibc_cos(double x) { int o = 0; return rpp_glibc_cos_raw(x, &o); }
 RPP_HD static inline double rpp_glibc_atan2(double y, double x) { int o = 0; return rpp_glibc_atan2_raw(y, x, &o); }
 RPP_HD static inline double rpp_glibc_pow(double x, double y) { int o = 0; return rpp_glibc_pow_raw(x, y, &o); }
+RPP_HD static inline double rpp_glibc_acos(double x) { int o = 0; return rpp_glibc_acos_raw(x, &o); }
 """)
     print("wrote", a.out)
     return 0
