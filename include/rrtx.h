@@ -8,6 +8,7 @@
  *   10_path_planning_01_rrt_01_simple.py   RRT.planning            :71-101
  *   10_path_planning_01_rrt_04_rrt_star.py RRT.planning            :1036-1084
  *   10_path_planning_01_rrt_07_informed_rrt_star.py RRT.informed_rrt_star_search :1044-1108
+ *   10_path_planning_01_rrt_05_rrt_star_dubins_path.py RRT.planning :1416-1456
  * Each entry point names the reference interface it replaces.  Plain pointers
  * and sizes only; the caller owns every host buffer, the library owns device
  * memory behind the opaque handle.  Every function returns 0 or a negative
@@ -37,7 +38,8 @@ enum {
 
 enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
        RRTX_ALGO_RRT_STAR = 1,  /* rrt_04 RRT.planning :1036-1084 */
-       RRTX_ALGO_INFORMED = 2   /* rrt_07 RRT.informed_rrt_star_search :1044-1108 */ };
+       RRTX_ALGO_INFORMED = 2,  /* rrt_07 RRT.informed_rrt_star_search :1044-1108 */
+       RRTX_ALGO_DUBINS = 3     /* rrt_05 RRT.planning :1416-1456 (RRT*-Dubins; start[2]/goal[2] = yaw) */ };
 enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
        RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
 
@@ -68,7 +70,8 @@ typedef struct rrtx_params {
    * c_min = math.hypot(start - goal) (rrt_07:1054); the host computes both exactly as the reference does. */
   double informed_rot[4];
   double informed_c_min;
-  double reserved_d[3];
+  /* RRTX_ALGO_DUBINS only (rrt_05:1371-1373, 1411-1413) */
+  double curvature, goal_yaw_th, goal_xy_th;
 } rrtx_params;
 
 /* Aggregate counters over all instances of the last rrtx_plan(). */
@@ -119,6 +122,11 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
 int rrtx_get_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status);
 /* device pointer + byte size of the packed result table (n_instances x {f64 cost, i32 n, i32 status}) */
 int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes);
+/* RRTX_ALGO_DUBINS: node yaw (rrt_05 Node.yaw) and the stored edge polylines (Node.path_x / path_y, :1472-1474):
+ * plen[i] points per node, concatenated in node order into px/py. */
+int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap);
+int rrtx_get_polylines(rrtx_handle* h, int32_t instance, int32_t* plen, int32_t cap_nodes, double* px, double* py,
+                       int64_t cap_points, int64_t* n_points_out);
 /* Sobol index (RRT.sobol_inter_, rrt_04:995,1148) after planning */
 int rrtx_get_sobol_index(rrtx_handle* h, int32_t instance, int64_t* index);
 int rrtx_get_stats(rrtx_handle* h, rrtx_stats* st);

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
 RRTX_ABI_VERSION = 1
-ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED = 0, 1, 2
+ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS = 0, 1, 2, 3
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
 ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC = 1, 2, 4, 8
 ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
@@ -21,7 +21,7 @@ ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP
 
 EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_plan", "rrtx_get_tree",
-           "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_stats",
+           "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math"]
 
 
@@ -35,7 +35,8 @@ class Params(C.Structure):
                 ("expand_dis", C.c_double), ("path_resolution", C.c_double),
                 ("play_area", C.c_double * 4), ("robot_radius", C.c_double),
                 ("connect_circle_dist", C.c_double), ("informed_rot", C.c_double * 4),
-                ("informed_c_min", C.c_double), ("reserved_d", C.c_double * 3)]
+                ("informed_c_min", C.c_double), ("curvature", C.c_double), ("goal_yaw_th", C.c_double),
+                ("goal_xy_th", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -78,6 +79,8 @@ def load():
     L.rrtx_get_results.argtypes = [vp, vp, vp, vp]
     L.rrtx_results_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
     L.rrtx_get_sobol_index.argtypes = [vp, i32, i64p]
+    L.rrtx_get_yaw.argtypes = [vp, i32, vp, i32]
+    L.rrtx_get_polylines.argtypes = [vp, i32, vp, i32, vp, vp, C.c_int64, i64p]
     L.rrtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rrtx_enable_trace.argtypes = [vp, i32]
     L.rrtx_get_trace.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
@@ -101,7 +104,8 @@ class Handle:
 
     def __init__(self, algo, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
                  play_area=None, robot_radius=0.0, sampler=SAMPLER_MT, connect_circle_dist=50.0,
-                 search_until_max_iter=False, n_instances=1, device=0, informed_rot=None, informed_c_min=0.0):
+                 search_until_max_iter=False, n_instances=1, device=0, informed_rot=None, informed_c_min=0.0,
+                 curvature=1.0, goal_yaw_th=0.0, goal_xy_th=0.0):
         self.L = load()
         p = Params()
         p.abi_version = RRTX_ABI_VERSION
@@ -125,6 +129,7 @@ class Handle:
             for i in range(4):
                 p.informed_rot[i] = float(informed_rot[i])
         p.informed_c_min = float(informed_c_min)
+        p.curvature, p.goal_yaw_th, p.goal_xy_th = float(curvature), float(goal_yaw_th), float(goal_xy_th)
         self.params = p
         self.n_instances = int(n_instances)
         self.max_iter = int(max_iter)
@@ -214,6 +219,23 @@ class Handle:
         p = C.c_void_p(); b = C.c_int64()
         self._chk(self.L.rrtx_results_device_ptr(self._h, C.byref(p), C.byref(b)), "rrtx_results_device_ptr")
         return p.value, b.value
+
+    def get_yaw(self, instance=0):
+        n = C.c_int32()
+        self._chk(self.L.rrtx_get_tree(self._h, instance, None, None, None, None, 0, C.byref(n)), "rrtx_get_tree")
+        yaw = np.zeros(n.value)
+        self._chk(self.L.rrtx_get_yaw(self._h, instance, yaw.ctypes.data, n.value), "rrtx_get_yaw")
+        return yaw
+
+    def get_polylines(self, instance=0):
+        n = C.c_int32()
+        self._chk(self.L.rrtx_get_tree(self._h, instance, None, None, None, None, 0, C.byref(n)), "rrtx_get_tree")
+        tot = C.c_int64()
+        self._chk(self.L.rrtx_get_polylines(self._h, instance, None, 0, None, None, 0, C.byref(tot)), "rrtx_get_polylines")
+        plen = np.zeros(n.value, dtype=np.int32); px = np.zeros(tot.value); py = np.zeros(tot.value)
+        self._chk(self.L.rrtx_get_polylines(self._h, instance, plen.ctypes.data, n.value, px.ctypes.data, py.ctypes.data,
+                                            tot.value, C.byref(tot)), "rrtx_get_polylines")
+        return plen, px, py
 
     def get_sobol_index(self, instance=0):
         v = C.c_int64()

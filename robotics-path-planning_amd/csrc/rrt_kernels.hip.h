@@ -91,6 +91,7 @@ struct Ctx {
 };
 
 struct Sh {
+  static constexpr int kNU = NU_MAX;
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   rpp::Edge edge[EB];
@@ -356,9 +357,10 @@ __device__ __forceinline__ int hit_at(const int32_t* hits, const SH& sh, int h) 
 // first holder of their value, ascending.  mode 0: value = dx**2+dy**2 about
 // (qx,qy); mode 1: value = math.hypot(x-qx, y-qy).
 // Out: sh.uidx/uval[0..nu), sh.nu, sh.nvalid (= len of the reference's list).
+template <class SH>
 __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const double* __restrict__ y, double qx,
                                             double qy, double thr_exact, int mode, const int32_t* hits, int kraw,
-                                            Sh& sh) {
+                                            SH& sh) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
     sh.nu = 0;
@@ -415,16 +417,16 @@ __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const 
     if (first) {
       const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       int p = off + __popcll(mf & lt_mask);
-      if (p < NU_MAX) {
+      if (p < SH::kNU) {
         sh.uval[p] = v;
         sh.uidx[p] = idx;
       }
     }
     __syncthreads();
     if (tid == 0) {
-      if (tot > NU_MAX) {
+      if (tot > SH::kNU) {
         sh.overflow = 1;
-        tot = NU_MAX;
+        tot = SH::kNU;
       }
       sh.nu = tot;
     }

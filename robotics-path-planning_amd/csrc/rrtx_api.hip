@@ -16,6 +16,7 @@
 #include "rrt_kernels.hip.h"
 #include "rrt_star_v2.hip.h"
 #include "rrt_informed.hip.h"
+#include "rrt_dubins.hip.h"
 
 using rppk::Ctx;
 using rppk::Inst;
@@ -55,6 +56,7 @@ struct rrtx_handle {
   std::vector<void*> allocs;
   int chunk_iters = 1024;
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
+  rppd::DubArgs da;         // RRT*-Dubins device arrays
 };
 
 #define HIPCHK(h, expr)                                                                      \
@@ -105,7 +107,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if (!p || !out) return RRTX_E_INVALID;
   *out = nullptr;
   if (p->abi_version != RRTX_ABI_VERSION) return RRTX_E_INVALID;
-  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED) return RRTX_E_INVALID;
+  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS) return RRTX_E_INVALID;
   if (p->n_instances < 1 || p->max_iter < 0 || !(p->path_resolution > 0.0) || !(p->expand_dis >= 0.0))
     return RRTX_E_INVALID;
   int ndev = 0;
@@ -183,6 +185,24 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   }
   if (p->algo == RRTX_ALGO_INFORMED) {
     if ((rc = dalloc(h, &h->cbest, h->n_inst))) return rc;
+  }
+  memset(&h->da, 0, sizeof(h->da));
+  if (p->algo == RRTX_ALGO_DUBINS) {
+    rppd::DubArgs& d = h->da;
+    d.pool_cap = 128 * cap + 4096;   // polyline points per instance (edges replaced by rewire stay allocated)
+    if ((rc = dalloc(h, &d.yaw, tot))) return rc;
+    if ((rc = dalloc(h, &d.poff, tot))) return rc;
+    if ((rc = dalloc(h, &d.plen, tot))) return rc;
+    if ((rc = dalloc(h, &d.pool_x, (size_t)d.pool_cap * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.pool_y, (size_t)d.pool_cap * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.pool_used, h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.spx, (size_t)rppd::PMAX * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.spy, (size_t)rppd::PMAX * h->n_inst))) return rc;
+    d.curvature = p->curvature;
+    d.goal_yaw_th = p->goal_yaw_th;
+    d.goal_xy_th = p->goal_xy_th;
+    d.start_yaw = p->start[2];
+    d.goal_yaw = p->goal[2];
   }
   HIPCHK(h, hipMemcpy(dr2, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
   // default per-instance state: ctor start/goal, RNG seeded with the instance number
@@ -321,6 +341,7 @@ int rrtx_plan(rrtx_handle* h) {
     std::vector<double> inf(B, INFINITY);
     HIPCHK(h, hipMemcpy(h->cbest, inf.data(), sizeof(double) * B, hipMemcpyHostToDevice));
   }
+  if (c.algo == RRTX_ALGO_DUBINS) HIPCHK(h, hipMemset(h->da.pool_used, 0, sizeof(int64_t) * B));
   rppi::InformedArgs ia;
   for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
   ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
@@ -331,6 +352,8 @@ int rrtx_plan(rrtx_handle* h) {
     if (c.algo == RRTX_ALGO_INFORMED)
       hipLaunchKernelGGL(rppi::rrt_informed_kernel, dim3(B), dim3(rppi::TPB), 0, h->stream, c, ia, h->cbest,
                          h->chunk_iters);
+    else if (c.algo == RRTX_ALGO_DUBINS)
+      hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(B), dim3(rppd::TPB), 0, h->stream, c, h->da, h->chunk_iters);
     else
       hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);
     HIPCHK(h, hipGetLastError());
@@ -415,6 +438,42 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
     *n_out = 0;
     return RRTX_OK;
   }
+  if (h->p.algo == RRTX_ALGO_DUBINS) {
+    // generate_final_course (rrt_05:1512-1521): [goal] + reversed edge polylines up the parent chain + [start]
+    const int n = I.n;
+    const int64_t off = (int64_t)instance * h->stride;
+    std::vector<int32_t> par(n), plen(n);
+    std::vector<int64_t> poff(n);
+    HIPCHK(h, hipMemcpy(par.data(), h->c.parent + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(plen.data(), h->da.plen + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(poff.data(), h->da.poff + off, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+    int64_t total = 2;
+    for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) total += plen[nd];
+    *n_out = (int32_t)total;
+    if (!xy) return RRTX_OK;
+    if (cap_points < total) return RRTX_E_CAPACITY;
+    int64_t k = 0;
+    xy[0] = I.goal[0];
+    xy[1] = I.goal[1];
+    k = 1;
+    std::vector<double> bx, by;
+    for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) {
+      bx.resize(plen[nd]);
+      by.resize(plen[nd]);
+      HIPCHK(h, hipMemcpy(bx.data(), h->da.pool_x + (int64_t)instance * h->da.pool_cap + poff[nd],
+                          sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
+      HIPCHK(h, hipMemcpy(by.data(), h->da.pool_y + (int64_t)instance * h->da.pool_cap + poff[nd],
+                          sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
+      for (int q = plen[nd] - 1; q >= 0; q--) {
+        xy[2 * k] = bx[q];
+        xy[2 * k + 1] = by[q];
+        k++;
+      }
+    }
+    xy[2 * k] = I.start[0];
+    xy[2 * k + 1] = I.start[1];
+    return RRTX_OK;
+  }
   *n_out = I.path_n;
   if (!xy) return RRTX_OK;
   if (cap_points < I.path_n) return RRTX_E_CAPACITY;
@@ -462,6 +521,54 @@ int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes) {
   if (!h || !dptr || !bytes) return RRTX_E_INVALID;
   *dptr = (void*)h->c.results;
   *bytes = (int64_t)sizeof(Result) * h->n_inst;
+  return RRTX_OK;
+}
+
+int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap) {
+  if (!h || !yaw || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (!h->planned || h->p.algo != RRTX_ALGO_DUBINS) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Result r;
+  HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));
+  if (cap < r.n_nodes) return RRTX_E_CAPACITY;
+  HIPCHK(h, hipMemcpy(yaw, h->da.yaw + (int64_t)instance * h->stride, sizeof(double) * r.n_nodes, hipMemcpyDeviceToHost));
+  return RRTX_OK;
+}
+
+int rrtx_get_polylines(rrtx_handle* h, int32_t instance, int32_t* plen, int32_t cap_nodes, double* px, double* py,
+                       int64_t cap_points, int64_t* n_points_out) {
+  if (!h || !n_points_out || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (!h->planned || h->p.algo != RRTX_ALGO_DUBINS) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Result r;
+  HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));
+  const int n = r.n_nodes;
+  const int64_t off = (int64_t)instance * h->stride;
+  std::vector<int32_t> pl(n);
+  std::vector<int64_t> po(n);
+  HIPCHK(h, hipMemcpy(pl.data(), h->da.plen + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(po.data(), h->da.poff + off, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+  int64_t total = 0;
+  for (int i = 0; i < n; i++) total += pl[i];
+  *n_points_out = total;
+  if (!plen && !px && !py) return RRTX_OK;
+  if (cap_nodes < n || cap_points < total) return RRTX_E_CAPACITY;
+  int64_t used = 0;
+  HIPCHK(h, hipMemcpy(&used, h->da.pool_used + instance, sizeof(int64_t), hipMemcpyDeviceToHost));
+  std::vector<double> bx(used), by(used);
+  if (used) {
+    HIPCHK(h, hipMemcpy(bx.data(), h->da.pool_x + (int64_t)instance * h->da.pool_cap, sizeof(double) * used, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(by.data(), h->da.pool_y + (int64_t)instance * h->da.pool_cap, sizeof(double) * used, hipMemcpyDeviceToHost));
+  }
+  int64_t w = 0;
+  for (int i = 0; i < n; i++) {
+    if (plen) plen[i] = pl[i];
+    for (int q = 0; q < pl[i]; q++) {
+      if (px) px[w] = bx[po[i] + q];
+      if (py) py[w] = by[po[i] + q];
+      w++;
+    }
+  }
   return RRTX_OK;
 }
 

@@ -338,6 +338,101 @@ class InformedRRTStar:
         return get_path_length(path)
 
 
+class DubinsNode:
+    """rrt_05's RRT.Node (:1336-1349): pose + the sampled polyline of the edge from its parent."""
+
+    def __init__(self, x, y, yaw):
+        self.x = x
+        self.y = y
+        self.path_x = []
+        self.path_y = []
+        self.parent = None
+        self.cost = 0.0
+        self.yaw = yaw
+        self.path_yaw = []
+
+
+class RRTStarDubins:
+    """Drop-in for rrt_05's `RRT` (10_path_planning_01_rrt_05_rrt_star_dubins_path.py:1335-1795).
+
+    `planning(animation, search_until_max_iter=True)` as the reference's driver calls it; the sampler is always
+    pseudo-random (the reference never calls its Sobol variant, :1426) and edge costs are Euclidean (:1777)."""
+    Node = DubinsNode
+    AreaBounds = AreaBounds
+
+    def __init__(self, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
+                 goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=True,
+                 connect_circle_dist=50.0, search_until_max_iter=False, curvature=1.0,
+                 goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, device=0):
+        self.start = DubinsNode(start[0], start[1], start[2])
+        self.end = DubinsNode(goal[0], goal[1], goal[2])
+        self.min_rand = rand_area[0]
+        self.max_rand = rand_area[1]
+        self.play_area = AreaBounds(play_area) if play_area is not None else None
+        self.expand_dis = expand_dis
+        self.path_resolution = path_resolution
+        self.goal_sample_rate = goal_sample_rate
+        self.max_iter = max_iter
+        self.obstacle_list = obstacle_list
+        self.node_list = []
+        self.robot_radius = robot_radius
+        self.sobol_sampler = sobol_sampler
+        self.sobol_inter_ = 0
+        self.connect_circle_dist = connect_circle_dist
+        self.search_until_max_iter = search_until_max_iter
+        self.curvature = curvature
+        self.goal_yaw_th = goal_yaw_th
+        self.goal_xy_th = goal_xy_th
+        self.device = device
+        self.stats = None
+        self._trace = False
+        self.trace = None
+
+    def planning(self, animation=True, search_until_max_iter=True):
+        if not search_until_max_iter:
+            raise NotImplementedError("rrt_05's early-exit mode is not built yet (the driver never uses it)")
+        h = _abi.Handle(_abi.ALGO_DUBINS, [self.start.x, self.start.y, self.start.yaw],
+                        [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], self.expand_dis,
+                        self.path_resolution, self.goal_sample_rate, self.max_iter, robot_radius=self.robot_radius,
+                        connect_circle_dist=self.connect_circle_dist, search_until_max_iter=True, n_instances=1,
+                        device=self.device, curvature=self.curvature, goal_yaw_th=self.goal_yaw_th,
+                        goal_xy_th=self.goal_xy_th)
+        try:
+            h.set_obstacles(self.obstacle_list)
+            st = random.getstate()
+            h.set_rng_state(0, st)
+            if self._trace:
+                h.enable_trace(0)
+            h.plan()
+            random.setstate(h.get_rng_state(0, st[2]))
+            x, y, cost, parent = h.get_tree(0)
+            yaw = h.get_yaw(0)
+            plen, px, py = h.get_polylines(0)
+            nodes, off = [], 0
+            for i in range(len(x)):
+                nd = DubinsNode(float(x[i]), float(y[i]), float(yaw[i]))
+                nd.cost = float(cost[i])
+                nd.path_x = px[off:off + plen[i]]
+                nd.path_y = py[off:off + plen[i]]
+                off += int(plen[i])
+                nodes.append(nd)
+            for i, nd in enumerate(nodes):
+                nd.parent = nodes[int(parent[i])] if parent[i] >= 0 else None
+            self.node_list = nodes
+            self.tree = (x, y, cost, parent)
+            self.yaw = yaw
+            self.polylines = (plen, px, py)
+            path = h.get_path(0)
+            self.stats = h.get_stats()
+            if self._trace:
+                self.trace = h.get_trace()
+        finally:
+            h.close()
+        return None if path is None else [[float(a), float(b)] for a, b in path]
+
+    plan = planning
+
+
 def get_path_length(path):
     """rrt_04:1391-1399."""
     le = 0

@@ -12,6 +12,7 @@ planner = importlib.import_module("robotics-path-planning_amd.planner")
 RRT = _pkg.RRT
 RRTStar = _pkg.RRTStar
 RRTSobol = _pkg.RRTSobol
+RRTStarDubins = _pkg.RRTStarDubins
 InformedRRTStar = _pkg.InformedRRTStar
 informed_rotation = _pkg.informed_rotation
 BatchPlanner = _pkg.BatchPlanner

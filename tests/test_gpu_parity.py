@@ -223,3 +223,58 @@ def test_informed_host_class_drop_in(gpu):
     assert rrt.get_path_len(path) == 17.33495114327498
     assert rrt.node_list[5].parent == int(g["parent"][5]) and rrt.node_list[0].parent is None
     assert random.getstate()[1][624] == int(g["rng_pos_after"])
+
+
+@pytest.mark.parametrize("path", util.golden_files("rrt05"), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_dubins_matches_reference_golden(gpu, path):
+    """rrt_05 RRT*-Dubins on the GPU vs the reference goldens: poses, costs, parents, every stored edge polyline,
+    the final course and the RNG state (ints exact; doubles bit-exact on this image, contract 1e-6)."""
+    g = util.load_golden(path)
+    out = util.run_gpu_dubins(g, [int(g["seed"])], trace_instance=0)
+    d = util.first_trace_divergence(out["trace"], g["tr_rx"], g["tr_ry"], g["tr_nearest"])
+    assert d is None, "first divergent iteration %d" % d
+    x, y, cost, parent = out["trees"][0]
+    assert len(x) == len(g["x"]) and np.array_equal(parent, g["parent"])
+    assert np.allclose(x, g["x"], rtol=0, atol=1e-6) and np.allclose(out["yaws"][0], g["yaw"], rtol=0, atol=1e-6)
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(out["yaws"][0], g["yaw"])
+    plen, px, py = out["polys"][0]
+    assert np.array_equal(plen, g["poly_len"]) and np.array_equal(px, g["poly_x"]) and np.array_equal(py, g["poly_y"])
+    p = out["paths"][0]
+    if len(g["path"]) == 0:
+        assert p is None
+    else:
+        assert p is not None and np.array_equal(p, g["path"])
+    st = out["rng"][0]
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
+def test_gpu_dubins_batch_equals_oracle(gpu):
+    import oracle
+    g = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it500.npz")
+    seeds = list(range(1, 9))
+    out = util.run_gpu_dubins(g, seeds, max_iter=400)
+    for i, s in enumerate(seeds):
+        r = oracle.plan_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], 400, seed=s)
+        util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % s)
+        assert np.array_equal(out["yaws"][i], r["yaw"])
+        assert np.array_equal(out["polys"][i][1], r["poly_x"])
+        assert (out["paths"][i] is None) == (r["path"] is None)
+        if r["path"] is not None:
+            assert np.array_equal(out["paths"][i], r["path"])
+
+
+def test_dubins_host_class_drop_in(gpu):
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it150.npz")
+    random.seed(42)
+    rrt = rrt_amd.RRTStarDubins(start=list(g["start"]), goal=list(g["goal"]),
+                                obstacle_list=[tuple(o) for o in g["obstacles"]], rand_area=list(g["rand_area"]),
+                                expand_dis=3.0, path_resolution=0.5, goal_sample_rate=10, max_iter=150,
+                                robot_radius=0.0, sobol_sampler=True, connect_circle_dist=50.0,
+                                search_until_max_iter=True, curvature=1.0)
+    path = rrt.planning(animation=False)
+    assert path is None and len(rrt.node_list) == 27
+    assert max(nd.cost for nd in rrt.node_list) == 8.634402421885998       # SURVEY.md section 10
+    assert random.getstate()[1][624] == int(g["rng_pos_after"])
