@@ -39,9 +39,10 @@ def main():
                     help="planning instances per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
     ap.add_argument("--obstacles", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations (the headline metric); c3: rrt_07 Informed RRT* "
-                         "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 1024 instances")
+                         "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 768 instances; "
+                         "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1024 instances")
     ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
@@ -55,8 +56,14 @@ def main():
     import numpy as np
     import util
     c3 = a.workload == "c3"
+    c5 = a.workload == "c5"
     if a.obstacles is None:
-        a.obstacles = 200 if c3 else 50
+        a.obstacles = 200 if c3 else (6 if c5 else 50)
+    if c5:
+        if "--max-iter" not in sys.argv:
+            a.max_iter = 5000
+        if "--instances" not in sys.argv:
+            a.instances = 1024
     if c3:
         if "--max-iter" not in sys.argv:
             a.max_iter = 20000
@@ -84,12 +91,20 @@ def main():
     if c3:
         kw = dict(algo="informed", start=[2, 2], goal=[98, 98], obstacles=util.synth_map(11, a.obstacles, 0.3, 1.5),
                   rand_area=[0, 100], expand_dis=0.5, goal_sample_rate=10, max_iter=a.max_iter, sobol=1)
+    if c5:   # rrt_05 driver constants (rrt_05:1804-1859)
+        kw = dict(algo="dubins", start=[0.0, 0.0, 0.0], goal=[10.0, 10.0, 0.0],
+                  obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)], rand_area=[-2, 15],
+                  expand_dis=3.0, goal_sample_rate=10, max_iter=a.max_iter)
     B = a.instances
     seeds = sharding.shard_seeds(rank, B)          # rank r owns seeds r*B+1 .. (r+1)*B, no exchange while planning
     cuda = torch.device("cuda", local_rank) if dist is not None else None
 
     def make_handle(max_iter):
-        if c3:
+        if c5:
+            h = A.Handle(A.ALGO_DUBINS, kw["start"], kw["goal"], kw["rand_area"], 3.0, 0.5, 10, max_iter, robot_radius=0.0,
+                         connect_circle_dist=50.0, search_until_max_iter=True, n_instances=B, device=device,
+                         curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5)
+        elif c3:
             c_min, c = rrt_amd.informed_rotation(kw["start"], kw["goal"])
             h = A.Handle(A.ALGO_INFORMED, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], 1.0,
                          kw["goal_sample_rate"], max_iter, sampler=A.SAMPLER_SOBOL, n_instances=B, device=device,
@@ -172,11 +187,13 @@ def main():
             pass
         line = {
             "metric": "%s collision-checked edge expansions/sec (unique edges evaluated on device), "
-                      "%d-iteration trees" % ("Informed RRT*" if c3 else "RRT*", a.max_iter),
+                      "%d-iteration trees" % ("RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"), a.max_iter),
             "value": value, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": steps_done, "warmup": a.warmup,
             "ms_per_step": 1e3 * tmax / max(steps_done, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("C3: rrt_07 Informed RRT*, Sobol sampler, %d circle obstacles (map_seed 11, radii "
+            "config": {"workload": ("C5: rrt_05 RRT*-Dubins, driver constants (%d obstacles, 17x17 area, curvature 1), "
+                                    "max_iter %d, %d instances/GPU (seeds 1..)" if c5 else
+                                    "C3: rrt_07 Informed RRT*, Sobol sampler, %d circle obstacles (map_seed 11, radii "
                                     "U(0.3,1.5)) on 100x100, expand_dis 0.5, max_iter %d, %d instances/GPU (seeds 1..)"
                                     if c3 else
                                     "C2: rrt_04 RRT*, %d circle obstacles (map_seed 7) on 100x100, expand_dis 2.0, "
@@ -191,7 +208,8 @@ def main():
             "iterations_per_s": iters * ngpu / tmax,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "rppi::rrt_informed_kernel" if c3 else "rppk2(s)::rrt_star_kernel_v2",
+                         "kernel": "rppd::rrt_dubins_kernel" if c5 else (
+                             "rppi::rrt_informed_kernel" if c3 else "rppk2(s)::rrt_star_kernel_v2"),
                          "launches": launches,
                          "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
                          "traffic_note": traffic_note,
@@ -205,7 +223,10 @@ def main():
         if not a.no_cpu_baseline:
             import oracle
             tc = time.perf_counter()
-            if c3:
+            if c5:
+                kc = dict(max_iter=min(a.cpu_iters, a.max_iter))
+                r = oracle.plan_dubins(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], kc["max_iter"], seed=1)
+            elif c3:
                 kc = dict(kw)
                 kc.pop("algo")
                 kc["max_iter"] = min(a.cpu_iters, a.max_iter)
