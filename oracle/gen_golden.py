@@ -368,3 +368,62 @@ def main05(only=""):
 def math_pi():
     import math
     return math.pi
+
+
+# ------------------------------------------------------------------------------------------------ rrt_08
+def run_rrt08(mod, name, obstacles, start, goal, rand_area, max_iter, seed):
+    """BIT* (rrt_08:138-566), driver-style BITStar(...).plan(animation=False)."""
+    random.seed(seed)
+    b = mod.BITStar(start=start, goal=goal, obstacleList=obstacles, randArea=rand_area, maxIter=max_iter,
+                    lowerLimit=[0.0, 0.0], upperLimit=[0.0, 10.0], resolution=1.0, eta=2.0)
+    tr = {"e0": [], "e1": []}
+    o_best = b.best_in_edge_queue
+    cm = {}
+    o_is = b.informed_sample
+
+    def best_hook():
+        e = o_best()
+        tr["e0"].append(float(e[0])); tr["e1"].append(float(e[1]))
+        return e
+
+    def is_hook(m, cMax, cMin, xCenter, C):
+        cm["C"] = np.array(C, dtype=np.float64); cm["cMin"] = float(cMin)
+        return o_is(m, cMax, cMin, xCenter, C)
+    b.best_in_edge_queue = best_hook
+    b.informed_sample = is_hook
+    t0 = time.time()
+    err = ""
+    path = None
+    with contextlib.redirect_stdout(io.StringIO()):
+        try:
+            path = b.plan(animation=False)
+        except Exception as e:  # noqa: BLE001  (the reference can raise IndexError on an empty queue)
+            err = type(e).__name__
+    dt = time.time() - t0
+    state = random.getstate()
+    vids = [float(v) for v in b.tree.vertices.keys()]
+    out = dict(algo="bitstar", seed=seed, obstacles=np.array(obstacles, dtype=np.float64),
+               start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
+               rand_area=np.array(rand_area, dtype=np.float64), max_iter=max_iter,
+               rot_c=cm["C"], c_min=cm["cMin"], error=err,
+               path=np.array(path if path else [], dtype=np.float64).reshape(-1, 2),
+               vertex_ids=np.array(vids), g_scores=np.array([float(b.g_scores[v]) for v in b.tree.vertices.keys()]),
+               parent_ids=np.array([float(b.nodes.get(v, -1)) for v in b.tree.vertices.keys()]),
+               n_edges=len(b.tree.edges), n_samples=len(b.samples),
+               sample_ids=np.array([float(k) for k in b.samples.keys()]),
+               tr_e0=np.array(tr["e0"]), tr_e1=np.array(tr["e1"]), ref_seconds=dt,
+               rng_pos_after=state[1][624], rng_word0_after=np.uint32(state[1][0]))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-24s verts=%d edges=%d path=%d samples=%d err=%r  %.2fs" % (name, len(vids), len(b.tree.edges),
+          len(out["path"]), len(b.samples), err, dt), flush=True)
+
+
+def main08(only=""):
+    m08 = ref_loader.load("rrt_08")
+    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]          # rrt_08:633-635
+    for seed, it, st, gl in ((42, 80, [-1.0, 0.0], [3.0, 8.0]), (1, 80, [-1.0, 0.0], [3.0, 8.0]),
+                             (2, 80, [-1.0, 0.0], [3.0, 8.0]), (3, 60, [0.0, 0.0], [6.0, 10.0]),
+                             (4, 40, [-1.0, 0.0], [3.0, 8.0]), (5, 80, [1.0, 1.0], [12.0, 12.0])):
+        n = "rrt08_s%d_it%d" % (seed, it)
+        if n.startswith(only):
+            run_rrt08(m08, n, obst, st, gl, [-2, 15], it, seed)

@@ -257,3 +257,53 @@ def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=
         res.update(tr_rx=trx[:t].copy(), tr_ry=try_[:t].copy(), tr_ryaw=tryaw[:t].copy(), tr_nearest=trn[:t].copy(),
                    tr_n_near=trk[:t].copy())
     return res
+
+
+class BOut(C.Structure):
+    _fields_ = [("path_xy", C.c_void_p), ("path_cap", C.c_int32), ("path_n", C.c_int32),
+                ("vertex_ids", C.c_void_p), ("g_scores", C.c_void_p), ("parent_ids", C.c_void_p),
+                ("vcap", C.c_int32), ("nv", C.c_int32), ("n_edges", C.c_int32), ("n_samples", C.c_int32),
+                ("tr_e0", C.c_void_p), ("tr_e1", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32),
+                ("error", C.c_int32)]
+
+
+def bitstar_rotation(start, goal):
+    """cMin and C of rrt_08:189-202 (numpy SVD), exactly as the reference computes them."""
+    import math
+    c_min = math.hypot(start[0] - goal[0], start[1] - goal[1]) / 1.5
+    a1 = np.array([[(goal[0] - start[0]) / c_min], [(goal[1] - start[1]) / c_min], [0]])
+    id1_t = np.array([1.0, 0.0, 0.0]).reshape(1, 3)
+    m = np.dot(a1, id1_t)
+    u, s, vh = np.linalg.svd(m, True, True)
+    c = np.dot(np.dot(u, np.diag([1.0, 1.0, np.linalg.det(u) * np.linalg.det(np.transpose(vh))])), vh)
+    return c_min, c
+
+
+def plan_bitstar(start, goal, obstacles, rand_area, max_iter=80, seed=None, rng=None, rot_c=None):
+    """One BITStar(...).plan(animation=False) call of rrt_08 on the oracle."""
+    L = lib()
+    L.orc_plan_bitstar.restype = C.c_int
+    L.orc_plan_bitstar.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]
+    st = np.array([float(start[0]), float(start[1])]); gl = np.array([float(goal[0]), float(goal[1])])
+    obst = np.ascontiguousarray(np.array(obstacles, dtype=np.float64).reshape(-1, 3))
+    if rng is None:
+        rng = mt_from_seed(seed)
+    if rot_c is None:
+        rot_c = bitstar_rotation(list(st), list(gl))[1]
+    rc_ = np.ascontiguousarray(np.array(rot_c, dtype=np.float64).reshape(9))
+    cap = 4096
+    path = np.zeros((cap, 2)); vid = np.zeros(cap); g = np.zeros(cap); par = np.zeros(cap)
+    tcap = 1 << 16
+    t0 = np.zeros(tcap); t1 = np.zeros(tcap)
+    o = BOut()
+    o.path_xy, o.path_cap = path.ctypes.data, cap
+    o.vertex_ids, o.g_scores, o.parent_ids, o.vcap = vid.ctypes.data, g.ctypes.data, par.ctypes.data, cap
+    o.tr_e0, o.tr_e1, o.tr_cap = t0.ctypes.data, t1.ctypes.data, tcap
+    rc = L.orc_plan_bitstar(st.ctypes.data, gl.ctypes.data, float(rand_area[0]), float(rand_area[1]), int(max_iter),
+                            obst.ctypes.data, len(obst), rc_.ctypes.data, C.byref(rng), C.byref(o))
+    if rc != 0:
+        raise RuntimeError("orc_plan_bitstar failed: %d" % rc)
+    return dict(path=path[:o.path_n].copy(), vertex_ids=vid[:o.nv].copy(), g_scores=g[:o.nv].copy(),
+                parent_ids=par[:o.nv].copy(), n_edges=o.n_edges, n_samples=o.n_samples, error=o.error,
+                tr_e0=t0[:min(o.tr_n, tcap)].copy(), tr_e1=t1[:min(o.tr_n, tcap)].copy(), rng=rng)

@@ -110,3 +110,28 @@ def test_dubins_rrt_star_oracle_matches_reference_golden(path):
     assert r["rng"].pos == int(g["rng_pos_after"]) and r["rng"].mt[0] == int(g["rng_word0_after"])
     n = len(g["tr_nearest"])
     assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])
+
+
+@pytest.mark.parametrize("path", util.golden_files("rrt08"), ids=lambda p: p.split("/")[-1][:-4])
+def test_bitstar_oracle_matches_reference_golden(path):
+    """rrt_08 BIT*: vertex insertion order, g-scores, parents, returned path, tree edge / sample counts, the whole
+    sequence of edges popped from the edge queue, and the RNG state equal the reference's."""
+    import oracle
+    g = util.load_golden(path)
+    c_min, c = oracle.bitstar_rotation(list(g["start"]), list(g["goal"]))
+    assert np.array_equal(c, g["rot_c"]) and c_min == float(g["c_min"])
+    r = oracle.plan_bitstar(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]), seed=int(g["seed"]))
+    assert r["error"] == (1 if str(g["error"]) else 0)
+    assert np.array_equal(r["vertex_ids"], g["vertex_ids"]) and np.array_equal(r["g_scores"], g["g_scores"])
+    assert np.array_equal(r["parent_ids"], g["parent_ids"])
+    assert np.array_equal(r["path"], g["path"])
+    assert r["n_edges"] == int(g["n_edges"]) and r["n_samples"] == int(g["n_samples"])
+    assert np.array_equal(r["tr_e0"], g["tr_e0"]) and np.array_equal(r["tr_e1"], g["tr_e1"])
+    assert r["rng"].pos == int(g["rng_pos_after"]) and r["rng"].mt[0] == int(g["rng_word0_after"])
+
+
+def test_bitstar_spot_value_survey_section10():
+    g = util.load_golden(util.GOLDEN + "/rrt08_s42_it80.npz")
+    p = g["path"]
+    assert len(p) == 9 and len(g["vertex_ids"]) == 80 and int(g["n_edges"]) == 79
+    assert np.allclose(p[:4], [[-1.0, 0.0], [-0.64, 1.16], [-0.28, 2.73], [-0.92, 4.49]], atol=1e-12)
