@@ -9,6 +9,7 @@
  *   10_path_planning_01_rrt_04_rrt_star.py RRT.planning            :1036-1084
  *   10_path_planning_01_rrt_07_informed_rrt_star.py RRT.informed_rrt_star_search :1044-1108
  *   10_path_planning_01_rrt_05_rrt_star_dubins_path.py RRT.planning :1416-1456
+ *   10_path_planning_01_rrt_08_batch_informed_rrt_star.py BITStar.plan :236-331
  * Each entry point names the reference interface it replaces.  Plain pointers
  * and sizes only; the caller owns every host buffer, the library owns device
  * memory behind the opaque handle.  Every function returns 0 or a negative
@@ -39,7 +40,8 @@ enum {
 enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
        RRTX_ALGO_RRT_STAR = 1,  /* rrt_04 RRT.planning :1036-1084 */
        RRTX_ALGO_INFORMED = 2,  /* rrt_07 RRT.informed_rrt_star_search :1044-1108 */
-       RRTX_ALGO_DUBINS = 3     /* rrt_05 RRT.planning :1416-1456 (RRT*-Dubins; start[2]/goal[2] = yaw) */ };
+       RRTX_ALGO_DUBINS = 3,    /* rrt_05 RRT.planning :1416-1456 (RRT*-Dubins; start[2]/goal[2] = yaw) */
+       RRTX_ALGO_BITSTAR = 4    /* rrt_08 BITStar.plan :236-331 (max_iter = maxIter; rand_area = randArea) */ };
 enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
        RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
 
@@ -110,6 +112,9 @@ int rrtx_get_rng_state(rrtx_handle* h, int32_t instance, uint32_t* mt624, int32_
 int rrtx_seed_instances(rrtx_handle* h, int32_t first, int32_t count, const uint64_t* seeds);
 /* per-instance start / goal for batches (default: the ctor's) */
 int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, const double* goal3);
+/* RRTX_ALGO_BITSTAR: per-instance rotation `C` (upper-left 2x2, row major) and cMin = hypot(start-goal)/1.5, computed
+ * by the host with numpy exactly as rrt_08:189-202 does (default: the ctor's informed_rot / informed_c_min). */
+int rrtx_set_instance_rotation(rrtx_handle* h, int32_t instance, const double* rot4, double c_min);
 /* replaces the body of RRT.planning(animation=False) for every instance; blocking. */
 int rrtx_plan(rrtx_handle* h);
 /* rrt.node_list as SoA: x, y, cost (f64), parent (i32, -1 = None); any pointer may be NULL. */

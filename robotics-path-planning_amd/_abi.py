@@ -13,14 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
 RRTX_ABI_VERSION = 1
-ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS = 0, 1, 2, 3
+ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR = 0, 1, 2, 3, 4
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
 ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC = 1, 2, 4, 8
 ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
           -5: "RRTX_E_STATE", -6: "RRTX_E_OVERFLOW"}
 
 EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
-           "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_plan", "rrtx_get_tree",
+           "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math"]
 
@@ -73,6 +73,7 @@ def load():
     L.rrtx_get_rng_state.argtypes = [vp, i32, vp, C.POINTER(i32)]
     L.rrtx_seed_instances.argtypes = [vp, i32, i32, vp]
     L.rrtx_set_instance.argtypes = [vp, i32, vp, vp]
+    L.rrtx_set_instance_rotation.argtypes = [vp, i32, vp, C.c_double]
     L.rrtx_plan.argtypes = [vp]
     L.rrtx_get_tree.argtypes = [vp, i32, vp, vp, vp, vp, i32, C.POINTER(i32)]
     L.rrtx_get_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
@@ -184,6 +185,11 @@ class Handle:
         self._chk(self.L.rrtx_set_instance(self._h, instance, C.cast(s, C.c_void_p) if s else None,
                                            C.cast(g, C.c_void_p) if g else None), "rrtx_set_instance")
 
+    def set_instance_rotation(self, instance, rot4, c_min):
+        r = (C.c_double * 4)(*[float(v) for v in rot4])
+        self._chk(self.L.rrtx_set_instance_rotation(self._h, instance, C.cast(r, C.c_void_p), float(c_min)),
+                  "rrtx_set_instance_rotation")
+
     def enable_trace(self, instance):
         self._chk(self.L.rrtx_enable_trace(self._h, instance), "rrtx_enable_trace")
 
@@ -254,7 +260,7 @@ class Handle:
 
     def get_trace(self):
         n = C.c_int32()
-        cap = self.max_iter + 1
+        cap = max(self.max_iter + 1, 1 << 16)
         rx = np.zeros(cap); ry = np.zeros(cap); ne = np.zeros(cap, dtype=np.int32); nn = np.zeros(cap, dtype=np.int32)
         self._chk(self.L.rrtx_get_trace(self._h, rx.ctypes.data, ry.ctypes.data, ne.ctypes.data, nn.ctypes.data, cap,
                                         C.byref(n)), "rrtx_get_trace")

@@ -17,6 +17,7 @@
 #include "rrt_star_v2.hip.h"
 #include "rrt_informed.hip.h"
 #include "rrt_dubins.hip.h"
+#include "rrt_bitstar.hip.h"
 
 using rppk::Ctx;
 using rppk::Inst;
@@ -57,6 +58,8 @@ struct rrtx_handle {
   int chunk_iters = 1024;
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
   rppd::DubArgs da;         // RRT*-Dubins device arrays
+  rppb::BitArgs ba;         // BIT* device arrays
+  std::vector<rpp::BitCfg> bcfg;
 };
 
 #define HIPCHK(h, expr)                                                                      \
@@ -107,7 +110,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if (!p || !out) return RRTX_E_INVALID;
   *out = nullptr;
   if (p->abi_version != RRTX_ABI_VERSION) return RRTX_E_INVALID;
-  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS) return RRTX_E_INVALID;
+  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS && p->algo != RRTX_ALGO_BITSTAR) return RRTX_E_INVALID;
   if (p->n_instances < 1 || p->max_iter < 0 || !(p->path_resolution > 0.0) || !(p->expand_dis >= 0.0))
     return RRTX_E_INVALID;
   int ndev = 0;
@@ -185,6 +188,29 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   }
   if (p->algo == RRTX_ALGO_INFORMED) {
     if ((rc = dalloc(h, &h->cbest, h->n_inst))) return rc;
+  }
+  memset(&h->ba, 0, sizeof(h->ba));
+  if (p->algo == RRTX_ALGO_BITSTAR) {
+    rppb::BitArgs& b = h->ba;
+    if ((rc = dalloc(h, &b.cfg, h->n_inst))) return rc;
+    if ((rc = dalloc(h, &b.dslab, (size_t)rppb::DSLAB * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &b.islab, (size_t)rppb::ISLAB * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &b.out_i, (size_t)8 * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &b.out_g, h->n_inst))) return rc;
+    b.trace_inst = -1;
+    h->bcfg.resize(h->n_inst);
+    for (int i = 0; i < h->n_inst; i++) {
+      rpp::BitCfg& c2 = h->bcfg[i];
+      memset(&c2, 0, sizeof(c2));
+      c2.start[0] = p->start[0]; c2.start[1] = p->start[1];
+      c2.goal[0] = p->goal[0]; c2.goal[1] = p->goal[1];
+      c2.rand_min = p->rand_min; c2.rand_max = p->rand_max;
+      for (int k = 0; k < 4; k++) c2.rot[k] = p->informed_rot[k];
+      c2.c_min = p->informed_c_min;
+      c2.c_min2 = py_sq_host(p->informed_c_min);
+      c2.num_cells = std::ceil((p->rand_max - p->rand_min) / 0.01);   // RTree num_cells (rrt_08:42-44, :165-168)
+      c2.max_iter = p->max_iter;
+    }
   }
   memset(&h->da, 0, sizeof(h->da));
   if (p->algo == RRTX_ALGO_DUBINS) {
@@ -274,11 +300,29 @@ int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, co
   if (start3) {
     I.start[0] = start3[0];
     I.start[1] = start3[1];
+    if (h->p.algo == RRTX_ALGO_BITSTAR) {
+      h->bcfg[instance].start[0] = start3[0];
+      h->bcfg[instance].start[1] = start3[1];
+    }
   }
   if (goal3) {
     I.goal[0] = goal3[0];
     I.goal[1] = goal3[1];
+    if (h->p.algo == RRTX_ALGO_BITSTAR) {
+      h->bcfg[instance].goal[0] = goal3[0];
+      h->bcfg[instance].goal[1] = goal3[1];
+    }
   }
+  return RRTX_OK;
+}
+
+int rrtx_set_instance_rotation(rrtx_handle* h, int32_t instance, const double* rot4, double c_min) {
+  if (!h || !rot4 || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (h->p.algo != RRTX_ALGO_BITSTAR) return RRTX_E_STATE;
+  rpp::BitCfg& c2 = h->bcfg[instance];
+  for (int k = 0; k < 4; k++) c2.rot[k] = rot4[k];
+  c2.c_min = c_min;
+  c2.c_min2 = py_sq_host(c_min);
   return RRTX_OK;
 }
 
@@ -314,6 +358,32 @@ int rrtx_plan(rrtx_handle* h) {
   double kms = 0.0;
   int64_t launches = 0;
   std::vector<Result> res(B);
+  if (c.algo == RRTX_ALGO_BITSTAR) {
+    // BIT*: one launch, one lane per instance (rrt_bitstar.hip.h); obstacle thresholds are size ** 2 (rrt_08:381)
+    for (int i = 0; i < B; i++) {
+      h->bcfg[i].m = c.m;
+      h->bcfg[i].ox = c.ox;
+      h->bcfg[i].oy = c.oy;
+      h->bcfg[i].othr = c.othr;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->ba.cfg, h->bcfg.data(), sizeof(rpp::BitCfg) * B, hipMemcpyHostToDevice, h->stream));
+    if (h->trace_inst >= 0 && !h->ba.tr_a) {
+      int rc2;
+      if ((rc2 = dalloc(h, &h->ba.tr_a, 1 << 16))) return rc2;
+      if ((rc2 = dalloc(h, &h->ba.tr_b, 1 << 16))) return rc2;
+      h->ba.tr_cap = 1 << 16;
+    }
+    h->ba.trace_inst = h->trace_inst;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(rppb::bitstar_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->ba, c.inst, c.results, B);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    kms += ms;
+    launches++;
+  }
   // RRT* with search_until_max_iter: the latency-lean iteration kernel runs every iteration; the general kernel
   // below then only performs the final goal search (rrt_04:1080-1084).  RRTX_KERNEL=v1 forces the general kernel.
   const char* kv = getenv("RRTX_KERNEL");
@@ -420,6 +490,31 @@ int rrtx_get_tree(rrtx_handle* h, int32_t instance, double* x, double* y, double
   HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));
   *n_out = r.n_nodes;
   if ((x || y || cost || parent) && cap < r.n_nodes) return RRTX_E_CAPACITY;
+  if (h->p.algo == RRTX_ALGO_BITSTAR) {
+    // tree.vertices in insertion order: coordinates of the grid ids (rrt_08:115-135), g-scores, `nodes` parents
+    const int n = r.n_nodes;
+    std::vector<double> vid(n), vg(n), vpar(n);
+    std::vector<int32_t> vh(n);
+    const double* d = h->ba.dslab + (int64_t)instance * rppb::DSLAB + 3LL * rppb::SC + 3LL * rppb::LC;
+    HIPCHK(h, hipMemcpy(vid.data(), d, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(vg.data(), d + rppb::VC, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(vpar.data(), d + 3LL * rppb::VC, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(vh.data(), h->ba.islab + (int64_t)instance * rppb::ISLAB, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    const rpp::BitCfg& bc = h->bcfg[instance];
+    for (int i = 0; i < n; i++) {
+      const double c1 = std::floor(vid[i] / bc.num_cells), c0 = std::floor((vid[i] - c1 * bc.num_cells) / 1);
+      if (x) x[i] = bc.rand_min + 0.01 * c0;
+      if (y) y[i] = bc.rand_min + 0.01 * c1;
+      if (cost) cost[i] = vg[i];
+      if (parent) {
+        parent[i] = -1;
+        if (vh[i])
+          for (int j = 0; j < n; j++)
+            if (vid[j] == vpar[i]) parent[i] = j;
+      }
+    }
+    return RRTX_OK;
+  }
   const int64_t off = (int64_t)instance * h->stride;
   if (x) HIPCHK(h, hipMemcpy(x, h->c.x + off, sizeof(double) * r.n_nodes, hipMemcpyDeviceToHost));
   if (y) HIPCHK(h, hipMemcpy(y, h->c.y + off, sizeof(double) * r.n_nodes, hipMemcpyDeviceToHost));
@@ -436,6 +531,17 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
   HIPCHK(h, hipMemcpy(&I, h->c.inst + instance, sizeof(I), hipMemcpyDeviceToHost));
   if (!(I.status & RRTX_ST_PATH)) {
     *n_out = 0;
+    return RRTX_OK;
+  }
+  if (h->p.algo == RRTX_ALGO_BITSTAR) {
+    int32_t oi[8];
+    HIPCHK(h, hipMemcpy(oi, h->ba.out_i + 8 * instance, sizeof(oi), hipMemcpyDeviceToHost));
+    *n_out = oi[3];
+    if (!xy || oi[3] == 0) return RRTX_OK;
+    if (cap_points < oi[3]) return RRTX_E_CAPACITY;
+    const double* d = h->ba.dslab + (int64_t)instance * rppb::DSLAB + 3LL * rppb::SC + 3LL * rppb::LC + 5LL * rppb::VC +
+                      2LL * rppb::EC;
+    HIPCHK(h, hipMemcpy(xy, d, sizeof(double) * 2 * oi[3], hipMemcpyDeviceToHost));
     return RRTX_OK;
   }
   if (h->p.algo == RRTX_ALGO_DUBINS) {
@@ -599,6 +705,15 @@ int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* neares
   if (!h || !n_out) return RRTX_E_INVALID;
   if (!h->planned || h->trace_inst < 0) return RRTX_E_STATE;
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->p.algo == RRTX_ALGO_BITSTAR) {   // rnd_x / rnd_y carry the ids of the popped edges (bestEdge[0], bestEdge[1])
+    int32_t oi[8];
+    HIPCHK(h, hipMemcpy(oi, h->ba.out_i + 8 * h->trace_inst, sizeof(oi), hipMemcpyDeviceToHost));
+    *n_out = oi[6];
+    if (cap < oi[6] || oi[6] > h->ba.tr_cap) return RRTX_E_CAPACITY;
+    if (rnd_x) HIPCHK(h, hipMemcpy(rnd_x, h->ba.tr_a, sizeof(double) * oi[6], hipMemcpyDeviceToHost));
+    if (rnd_y) HIPCHK(h, hipMemcpy(rnd_y, h->ba.tr_b, sizeof(double) * oi[6], hipMemcpyDeviceToHost));
+    return RRTX_OK;
+  }
   Inst I;
   HIPCHK(h, hipMemcpy(&I, h->c.inst + h->trace_inst, sizeof(I), hipMemcpyDeviceToHost));
   const int n = I.it;

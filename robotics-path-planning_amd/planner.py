@@ -433,6 +433,59 @@ class RRTStarDubins:
     plan = planning
 
 
+def bitstar_rotation(start_xy, goal_xy):
+    """cMin and C of rrt_08:189-202, computed with numpy exactly as the reference does."""
+    c_min = math.hypot(start_xy[0] - goal_xy[0], start_xy[1] - goal_xy[1]) / 1.5
+    a1 = np.array([[(goal_xy[0] - start_xy[0]) / c_min], [(goal_xy[1] - start_xy[1]) / c_min], [0]])
+    id1_t = np.array([1.0, 0.0, 0.0]).reshape(1, 3)
+    m = np.dot(a1, id1_t)
+    u, s, vh = np.linalg.svd(m, True, True)
+    c = np.dot(np.dot(u, np.diag([1.0, 1.0, np.linalg.det(u) * np.linalg.det(np.transpose(vh))])), vh)
+    return c_min, c
+
+
+class BITStar:
+    """Drop-in for rrt_08's `BITStar` (10_path_planning_01_rrt_08_batch_informed_rrt_star.py:138-566).
+    As in the reference, `lowerLimit`, `upperLimit`, `resolution` and `eta` are accepted and ignored (:165-168)."""
+
+    def __init__(self, start, goal, obstacleList, randArea, eta=2.0, maxIter=80, lowerLimit=None, upperLimit=None,
+                 resolution=0.01, device=0):
+        self.start = start
+        self.goal = goal
+        self.min_rand = randArea[0]
+        self.max_rand = randArea[1]
+        self.max_iIter = maxIter
+        self.obstacleList = obstacleList
+        self.eta = eta
+        self.device = device
+        self.stats = None
+        self.tree_arrays = None
+        self._trace = False
+        self.trace = None
+
+    def plan(self, animation=True):
+        c_min, c = bitstar_rotation(self.start, self.goal)
+        h = _abi.Handle(_abi.ALGO_BITSTAR, [self.start[0], self.start[1]], [self.goal[0], self.goal[1]],
+                        [self.min_rand, self.max_rand], 2.0, 1.0, 0, self.max_iIter, n_instances=1, device=self.device,
+                        informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+        try:
+            h.set_obstacles(self.obstacleList)
+            st = random.getstate()
+            h.set_rng_state(0, st)
+            if self._trace:
+                h.enable_trace(0)
+            h.plan()
+            random.setstate(h.get_rng_state(0, st[2]))
+            self.tree_arrays = h.get_tree(0)
+            path = h.get_path(0)
+            self.stats = h.get_stats()
+            if self._trace:
+                self.trace = h.get_trace()
+        finally:
+            h.close()
+        return [] if path is None else [[float(a), float(b)] for a, b in path]
+
+
 def get_path_length(path):
     """rrt_04:1391-1399."""
     le = 0

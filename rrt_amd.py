@@ -13,6 +13,8 @@ RRT = _pkg.RRT
 RRTStar = _pkg.RRTStar
 RRTSobol = _pkg.RRTSobol
 RRTStarDubins = _pkg.RRTStarDubins
+BITStar = _pkg.BITStar
+bitstar_rotation = _pkg.bitstar_rotation
 InformedRRTStar = _pkg.InformedRRTStar
 informed_rotation = _pkg.informed_rotation
 BatchPlanner = _pkg.BatchPlanner

@@ -71,3 +71,51 @@ def test_python_hypot_matches_oracle_hypot():
     b[::7] *= 1e-6
     for i in range(len(a)):
         assert L.orc_hypot(a[i], b[i]) == math.hypot(a[i], b[i])
+
+
+def test_bitstar_core_against_goldens_and_oracle(builddir):
+    """The product's BIT* core (rpp_bitstar.h), compiled for the host, reproduces the reference goldens and agrees
+    with the oracle on further seeds (vertex order, g-scores, parents, path, popped-edge sequence, RNG state)."""
+    import ctypes as C
+    import oracle
+    so = os.path.join(builddir, "libbitstar_host.so")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-mfma", "-I", CSRC,
+                    os.path.join(util.ROOT, "tests", "native", "bitstar_host.cpp"), "-o", so], check=True)
+    L = C.CDLL(so)
+
+    def run(start, goal, obst, rand_area, max_iter, seed):
+        c_min, c = oracle.bitstar_rotation([float(v) for v in start], [float(v) for v in goal])
+        st = np.array(start, dtype=np.float64); gl = np.array(goal, dtype=np.float64)
+        ob = np.ascontiguousarray(np.array(obst, dtype=np.float64).reshape(-1, 3))
+        rot = np.array([c[0, 0], c[0, 1], c[1, 0], c[1, 1]])
+        rng = oracle.mt_from_seed(seed)
+        mt = np.array(list(rng.mt), dtype=np.uint32); pos = C.c_int(rng.pos)
+        path = np.zeros((4096, 2)); vid = np.zeros(1024); vg = np.zeros(1024); vp = np.zeros(1024)
+        ta = np.zeros(1 << 16); tb = np.zeros(1 << 16)
+        pn = C.c_int(); nv = C.c_int(); tn = C.c_int(); ne = C.c_int(); ns = C.c_int(); er = C.c_int()
+        L.host_bitstar(st.ctypes.data_as(C.c_void_p), gl.ctypes.data_as(C.c_void_p), C.c_double(rand_area[0]),
+                       C.c_double(rand_area[1]), C.c_int(max_iter), ob.ctypes.data_as(C.c_void_p), C.c_int(len(ob)),
+                       rot.ctypes.data_as(C.c_void_p), C.c_double(c_min), mt.ctypes.data_as(C.c_void_p), C.byref(pos),
+                       path.ctypes.data_as(C.c_void_p), C.c_int(4096), C.byref(pn), vid.ctypes.data_as(C.c_void_p),
+                       vg.ctypes.data_as(C.c_void_p), vp.ctypes.data_as(C.c_void_p), C.c_int(1024), C.byref(nv),
+                       ta.ctypes.data_as(C.c_void_p), tb.ctypes.data_as(C.c_void_p), C.c_int(1 << 16), C.byref(tn),
+                       C.byref(ne), C.byref(ns), C.byref(er))
+        return dict(path=path[:pn.value].copy(), vertex_ids=vid[:nv.value].copy(), g_scores=vg[:nv.value].copy(),
+                    parent_ids=vp[:nv.value].copy(), tr_e0=ta[:tn.value].copy(), tr_e1=tb[:tn.value].copy(),
+                    n_edges=ne.value, n_samples=ns.value, error=er.value, pos=pos.value, w0=int(mt[0]))
+
+    for f in util.golden_files("rrt08"):
+        g = util.load_golden(f)
+        r = run(g["start"], g["goal"], g["obstacles"], [float(v) for v in g["rand_area"]], int(g["max_iter"]), int(g["seed"]))
+        assert np.array_equal(r["vertex_ids"], g["vertex_ids"]) and np.array_equal(r["g_scores"], g["g_scores"]), f
+        assert np.array_equal(r["parent_ids"], g["parent_ids"]) and np.array_equal(r["path"], g["path"]), f
+        assert np.array_equal(r["tr_e0"], g["tr_e0"]) and np.array_equal(r["tr_e1"], g["tr_e1"]), f
+        assert r["n_edges"] == int(g["n_edges"]) and r["n_samples"] == int(g["n_samples"])
+        assert r["pos"] == int(g["rng_pos_after"]) and r["w0"] == int(g["rng_word0_after"])
+    g = util.load_golden(util.GOLDEN + "/rrt08_s42_it80.npz")
+    for seed in range(100, 112):
+        r = run(g["start"], g["goal"], g["obstacles"], [-2.0, 15.0], 60, seed)
+        o = oracle.plan_bitstar(g["start"], g["goal"], g["obstacles"], [-2, 15], 60, seed=seed)
+        assert r["error"] == o["error"]
+        assert np.array_equal(r["vertex_ids"], o["vertex_ids"]) and np.array_equal(r["g_scores"], o["g_scores"])
+        assert np.array_equal(r["path"], o["path"]) and np.array_equal(r["tr_e0"], o["tr_e0"])

@@ -278,3 +278,75 @@ def test_dubins_host_class_drop_in(gpu):
     assert path is None and len(rrt.node_list) == 27
     assert max(nd.cost for nd in rrt.node_list) == 8.634402421885998
     assert random.getstate()[1][624] == int(g["rng_pos_after"])
+
+
+def _bit_coords(ids, rand_min=-2.0):
+    c1 = np.floor(ids / 1700.0)
+    c0 = np.floor((ids - c1 * 1700.0) / 1)
+    return rand_min + 0.01 * c0, rand_min + 0.01 * c1
+
+
+@pytest.mark.parametrize("path", util.golden_files("rrt08"), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_bitstar_matches_reference_golden(gpu, path):
+    """rrt_08 BIT* on the GPU vs the reference goldens: popped-edge sequence, tree vertices (grid coordinates),
+    g-scores, parents, returned path (start -> goal) and RNG state."""
+    g = util.load_golden(path)
+    out = util.run_gpu_bitstar([tuple(float(v) for v in o) for o in g["obstacles"]], [float(v) for v in g["rand_area"]],
+                               int(g["max_iter"]), [int(g["seed"])], [[float(v) for v in g["start"]]],
+                               [[float(v) for v in g["goal"]]], trace_instance=0)
+    tr = out["trace"]
+    assert np.array_equal(tr[0], g["tr_e0"]) and np.array_equal(tr[1], g["tr_e1"])
+    x, y, cost, parent = out["trees"][0]
+    gx, gy = _bit_coords(g["vertex_ids"])
+    assert len(x) == len(gx) and np.array_equal(x, gx) and np.array_equal(y, gy) and np.array_equal(cost, g["g_scores"])
+    want_parent = np.array([-1 if p < 0 else int(np.nonzero(g["vertex_ids"] == p)[0][0]) for p in g["parent_ids"]])
+    assert np.array_equal(parent, want_parent)
+    p = out["paths"][0]
+    if len(g["path"]) == 0:
+        assert p is None
+    else:
+        assert np.array_equal(p, g["path"])
+    st = out["rng"][0]
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
+def test_gpu_bitstar_batch_c4_style_equals_oracle(gpu):
+    """C4-style batch: per-instance start/goal from random.Random(2000+i) in [-1,14]^2 outside the
+    obstacles, planner seed 1000+i; every instance equals the oracle's run."""
+    import random
+    import oracle
+    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+
+    def free_point(rng):
+        while True:
+            x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
+            if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
+                return [x, y]
+    n = 24
+    starts, goals, seeds = [], [], []
+    for i in range(n):
+        rng = random.Random(2000 + i)
+        starts.append(free_point(rng))
+        goals.append(free_point(rng))
+        seeds.append(1000 + i)
+    out = util.run_gpu_bitstar(obst, [-2.0, 15.0], 80, seeds, starts, goals)
+    for i in range(n):
+        r = oracle.plan_bitstar(starts[i], goals[i], obst, [-2, 15], 80, seed=seeds[i])
+        x, y, cost, parent = out["trees"][i]
+        gx, gy = _bit_coords(r["vertex_ids"])
+        assert np.array_equal(x, gx) and np.array_equal(y, gy) and np.array_equal(cost, r["g_scores"]), i
+        p = out["paths"][i]
+        assert (p is None and len(r["path"]) == 0) or np.array_equal(p, r["path"]), i
+
+
+def test_bitstar_host_class_drop_in(gpu):
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt08_s42_it80.npz")
+    random.seed(42)
+    b = rrt_amd.BITStar(start=[-1.0, 0.0], goal=[3.0, 8.0], obstacleList=[tuple(o) for o in g["obstacles"]],
+                        randArea=[-2, 15], maxIter=80, lowerLimit=[0.0, 0.0], upperLimit=[0.0, 10.0], resolution=1.0,
+                        eta=2.0)
+    path = b.plan(animation=False)
+    assert len(path) == 9 and np.array_equal(np.array(path), g["path"])
+    assert random.getstate()[1][624] == int(g["rng_pos_after"])

@@ -179,3 +179,32 @@ def run_gpu_dubins(g, seeds, device=0, trace_instance=None, max_iter=None):
     finally:
         h.close()
     return out
+
+
+def run_gpu_bitstar(obstacles, rand_area, max_iter, seeds, starts, goals, device=0, trace_instance=None):
+    """BIT* (rrt_08) instances on the GPU through the C ABI; per-instance start / goal / rotation."""
+    import rrt_amd
+    A = rrt_amd._abi
+    c_min, c = rrt_amd.bitstar_rotation(starts[0], goals[0])
+    h = A.Handle(A.ALGO_BITSTAR, starts[0], goals[0], rand_area, 2.0, 1.0, 0, max_iter, n_instances=len(seeds),
+                 device=device, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+    try:
+        h.set_obstacles(obstacles)
+        h.seed_instances(seeds)
+        for i in range(len(seeds)):
+            cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])
+            h.set_instance(i, starts[i], goals[i])
+            h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        if trace_instance is not None:
+            h.enable_trace(trace_instance)
+        h.plan()
+        out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], paths=[], rng=[])
+        for i in range(len(seeds)):
+            out["trees"].append(h.get_tree(i))
+            out["paths"].append(h.get_path(i))
+            out["rng"].append(h.get_rng_state(i))
+        if trace_instance is not None:
+            out["trace"] = h.get_trace()
+    finally:
+        h.close()
+    return out
