@@ -55,7 +55,8 @@ struct Inst {  // persistent per-instance state (global memory)
   rpp::MT rng;
   rpp::Sobol sobol;
   double start[2], goal[2];
-  int32_t n, it, status, goal_node, path_n, pad_;
+  int32_t n, it, status, goal_node, path_n;
+  int32_t first_goal;   // lowest index of a node lying exactly on the goal (-1 none yet, -2 unknown); f32-mirror path only
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
       exact_rescans, alg_bytes2;
   int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
@@ -88,6 +89,9 @@ struct Ctx {
   int32_t trace_inst;
   double *tr_rx, *tr_ry;
   int32_t *tr_near, *tr_nn;
+  // f32 mirror of x[], y[] (prefilter of the streaming pass, rrt_star_v2_body.inc) and its distance margin
+  float *xf, *yf;
+  double f32_m;
 };
 
 struct Sh {
@@ -1136,6 +1140,10 @@ __global__ void rrt_init_kernel(Ctx c) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < c.stride; i += (int64_t)gridDim.x * blockDim.x) {
     c.x[off + i] = inf;
     c.y[off + i] = inf;
+    if (c.xf) {
+      c.xf[off + i] = __builtin_inff();
+      c.yf[off + i] = __builtin_inff();
+    }
   }
 }
 __global__ void rrt_root_kernel(Ctx c, int ninst) {
@@ -1145,6 +1153,11 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   Inst* I = c.inst + inst;
   c.x[off] = I->start[0];
   c.y[off] = I->start[1];
+  if (c.xf) {
+    c.xf[off] = (float)I->start[0];
+    c.yf[off] = (float)I->start[1];
+  }
+  I->first_goal = -1;
   c.cost[off] = 0.0;
   c.parent[off] = -1;
   c.first_child[off] = -1;

@@ -147,6 +147,11 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if ((rc = dalloc(h, &c.prev_sib, tot))) return rc;
   if ((rc = dalloc(h, &c.hits, tot))) return rc;
   if ((rc = dalloc(h, &c.stack, tot))) return rc;
+  if (p->algo == RRTX_ALGO_RRT_STAR && p->search_until_max_iter) {
+    // float mirror of the coordinates for the prefiltered streaming pass (rrt_star_v2_body.inc)
+    if ((rc = dalloc(h, &c.xf, tot))) return rc;
+    if ((rc = dalloc(h, &c.yf, tot))) return rc;
+  }
   if ((rc = dalloc(h, &c.results, h->n_inst))) return rc;
   c.path_cap = (int32_t)(cap + 1 < 8192 ? cap + 1 : 8192);
   if ((rc = dalloc(h, &c.path_xy, (size_t)h->n_inst * c.path_cap * 2))) return rc;
@@ -392,12 +397,33 @@ int rrtx_plan(rrtx_handle* h) {
     // workgroup shape: 128 threads per instance once more than 1024 instances want to be resident (8 per CU)
     int tpb = (B > 1280 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
     if (const char* e = getenv("RRTX_TPB")) tpb = (atoi(e) == 128 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
+    // f32-mirror prefilter (default on; RRTX_F32=0 streams the f64 arrays): margin = 2^-20 * largest coordinate
+    // magnitude any node or sample can have (see scan2f)
+    bool f32 = c.xf != nullptr;
+    if (const char* e = getenv("RRTX_F32")) f32 = f32 && atoi(e) != 0;
+    {
+      double mag = fabs(c.rand_min) > fabs(c.rand_max) ? fabs(c.rand_min) : fabs(c.rand_max);
+      for (int i = 0; i < B; i++) {
+        const Inst& I = h->host_inst[i];
+        const double v[4] = {I.start[0], I.start[1], I.goal[0], I.goal[1]};
+        for (double q : v)
+          if (fabs(q) > mag) mag = fabs(q);
+      }
+      c.f32_m = ldexp(mag > 1.0 ? mag : 1.0, -20);
+    }
     for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->chunk_iters) {
       HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-      if (tpb == 128)
-        hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
-      else
-        hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->chunk_iters);
+      if (tpb == 128) {
+        if (f32)
+          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
+        else
+          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
+      } else {
+        if (f32)
+          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->chunk_iters);
+        else
+          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->chunk_iters);
+      }
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipEventRecord(h->ev1, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));
