@@ -177,14 +177,20 @@ def main():
         achieved_2s = (alg_bytes2 / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
         traffic = None
         traffic_note = None
-        try:   # PMC traffic of the same workload, measured in separate rocprofv3 --pmc passes (profiles/r1_traffic.json)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if tj["config"]["instances_per_gpu"] == B and tj["config"]["max_iter"] == a.max_iter \
-                    and tj["config"]["obstacles"] == a.obstacles:
+        # PMC traffic of the same workload and kernel variant, measured in separate rocprofv3 --pmc passes
+        # (tools/profile_headline.sh -> profiles/*_traffic.json)
+        variant = "f64" if os.environ.get("RRTX_F32", "1") == "0" else "f32_mirror"
+        for tf in ("r1_f32_traffic.json", "r1_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+            except Exception:  # noqa: BLE001
+                continue
+            tc = tj["config"]
+            if tc["instances_per_gpu"] == B and tc["max_iter"] == a.max_iter and tc["obstacles"] == a.obstacles \
+                    and tc.get("variant", "f64") == variant and not (c3 or c5):
                 traffic = tj["hbm_bytes_per_step"] / 1e9 / (kernel_ms / 1e3 / max(steps_done, 1))
-                traffic_note = "HBM bytes/step %.4g from %s" % (tj["hbm_bytes_per_step"], "profiles/r1_traffic.json")
-        except Exception:  # noqa: BLE001
-            pass
+                traffic_note = "HBM bytes/step %.4g from profiles/%s" % (tj["hbm_bytes_per_step"], tf)
+                break
         line = {
             "metric": "%s collision-checked edge expansions/sec (unique edges evaluated on device), "
                       "%d-iteration trees" % ("RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"), a.max_iter),
@@ -214,7 +220,7 @@ def main():
                          "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
                          "traffic_note": traffic_note,
                          "survey_8d_two_scan_GBps": achieved_2s, "survey_8d_two_scan_frac": achieved_2s / 8000.0,
-                         "note": "achieved = single-pass algorithmic bytes (16*n per iteration: the near pass of "
+                         "note": "achieved = single-pass algorithmic bytes (8*n per iteration from the f32 coordinate mirror, 16*n with RRTX_F32=0: the near pass of "
                                  "iteration i also answers the nearest query of i+1) / kernel time; "
                                  "survey_8d_two_scan_* applies SURVEY 8(d)'s two-scan formula (32*n) to the same run",
                          "kernel_ms_per_step": kernel_ms / max(steps_done, 1)},
