@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=int(os.environ.get("RRTX_BENCH_INSTANCES", "2048")),
+    ap.add_argument("--instances", type=int, default=int(os.environ.get("RRTX_BENCH_INSTANCES", "4096")),
                     help="planning instances per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
     ap.add_argument("--obstacles", type=int, default=None)
@@ -180,7 +180,7 @@ def main():
         # PMC traffic of the same workload and kernel variant, measured in separate rocprofv3 --pmc passes
         # (tools/profile_headline.sh -> profiles/*_traffic.json)
         variant = "f64" if os.environ.get("RRTX_F32", "1") == "0" else "f32_mirror"
-        for tf in ("r1_f32_traffic.json", "r1_traffic.json"):
+        for tf in ("r1_t64_traffic.json", "r1_f32_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             except Exception:  # noqa: BLE001
@@ -225,6 +225,8 @@ def main():
                                  "survey_8d_two_scan_* applies SURVEY 8(d)'s two-scan formula (32*n) to the same run",
                          "kernel_ms_per_step": kernel_ms / max(steps_done, 1)},
             "steps_requested": a.steps, "warmup_max_iter": a.warmup_max_iter or a.max_iter,
+            "near_unique_max": stats.get("near_unique_max"), "f32_fallbacks_last_step": stats.get("f32_fallbacks"),
+            "exact_rescans_last_step": stats.get("exact_rescans"),
         }
         if not a.no_cpu_baseline:
             import oracle

@@ -58,7 +58,7 @@ struct Inst {  // persistent per-instance state (global memory)
   int32_t n, it, status, goal_node, path_n;
   int32_t first_goal;   // lowest index of a node lying exactly on the goal (-1 none yet, -2 unknown); f32-mirror path only
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
-      exact_rescans, alg_bytes2;
+      exact_rescans, alg_bytes2, nu_max, f32_fallbacks;
   int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
 };
 
@@ -92,6 +92,9 @@ struct Ctx {
   // f32 mirror of x[], y[] (prefilter of the streaming pass, rrt_star_v2_body.inc) and its distance margin
   float *xf, *yf;
   double f32_m;
+  // elen[i] = hypot(node i - its parent), exactly the value calc_new_cost (rrt_04:1375-1377) would compute now;
+  // kept by the v2 kernel so cost propagation needs no coordinates and no hypot
+  double* elen;
 };
 
 struct Sh {
@@ -1158,6 +1161,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
     c.yf[off] = (float)I->start[1];
   }
   I->first_goal = -1;
+  if (c.elen) c.elen[off] = 0.0;
   c.cost[off] = 0.0;
   c.parent[off] = -1;
   c.first_child[off] = -1;
@@ -1172,6 +1176,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   I->sobol.lastq[0] = I->sobol.lastq[1] = 0;
   I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
   I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = I->alg_bytes2 = 0;
+  I->nu_max = I->f32_fallbacks = 0;
   for (int k = 0; k < 16; k++) I->phase[k] = 0;
   c.results[inst].path_cost = 0.0;
   c.results[inst].n_nodes = 1;

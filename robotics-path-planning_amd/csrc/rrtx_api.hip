@@ -151,6 +151,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     // float mirror of the coordinates for the prefiltered streaming pass (rrt_star_v2_body.inc)
     if ((rc = dalloc(h, &c.xf, tot))) return rc;
     if ((rc = dalloc(h, &c.yf, tot))) return rc;
+    if ((rc = dalloc(h, &c.elen, tot))) return rc;   // cached parent-edge lengths (cost propagation)
   }
   if ((rc = dalloc(h, &c.results, h->n_inst))) return rc;
   c.path_cap = (int32_t)(cap + 1 < 8192 ? cap + 1 : 8192);
@@ -394,9 +395,14 @@ int rrtx_plan(rrtx_handle* h) {
   const char* kv = getenv("RRTX_KERNEL");
   const bool use_v2 = c.algo == RRTX_ALGO_RRT_STAR && c.until_max && !(kv && !strcmp(kv, "v1"));
   if (use_v2) {
-    // workgroup shape: 128 threads per instance once more than 1024 instances want to be resident (8 per CU)
-    int tpb = (B > 1280 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
-    if (const char* e = getenv("RRTX_TPB")) tpb = (atoi(e) == 128 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
+    // workgroup shape: fewer threads per instance once more instances want to be resident (8 / 16 workgroups per CU)
+    int tpb = 256;
+    if (B > 1280 && c.m <= rppk2s::MAX_OBS) tpb = 128;
+    if (B > 2560 && c.m <= rppk2t::MAX_OBS) tpb = 64;
+    if (const char* e = getenv("RRTX_TPB")) {
+      const int v = atoi(e);
+      tpb = (v == 64 && c.m <= rppk2t::MAX_OBS) ? 64 : (v == 128 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
+    }
     // f32-mirror prefilter (default on; RRTX_F32=0 streams the f64 arrays): margin = 2^-20 * largest coordinate
     // magnitude any node or sample can have (see scan2f)
     bool f32 = c.xf != nullptr;
@@ -413,7 +419,12 @@ int rrtx_plan(rrtx_handle* h) {
     }
     for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->chunk_iters) {
       HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-      if (tpb == 128) {
+      if (tpb == 64) {
+        if (f32)
+          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->chunk_iters);
+        else
+          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->chunk_iters);
+      } else if (tpb == 128) {
         if (f32)
           hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
         else
@@ -493,6 +504,8 @@ int rrtx_plan(rrtx_handle* h) {
     s.exact_rescans += I.exact_rescans;
     s.algorithmic_bytes_two_scan += I.alg_bytes2;
     s.total_nodes += I.n;
+    s.f32_fallbacks += I.f32_fallbacks;
+    if (I.nu_max > s.near_unique_max) s.near_unique_max = I.nu_max;
     if (I.status & RRTX_ST_OVERFLOW) overflow = true;
     for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];
   }

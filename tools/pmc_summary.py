@@ -21,7 +21,7 @@ from collections import defaultdict
 ap = argparse.ArgumentParser()
 ap.add_argument("dir")
 ap.add_argument("tag")
-ap.add_argument("--instances", type=int, default=2048)
+ap.add_argument("--instances", type=int, default=4096)
 ap.add_argument("--max-iter", type=int, default=105000)
 ap.add_argument("--obstacles", type=int, default=50)
 ap.add_argument("--variant", default="f32_mirror")
