@@ -63,7 +63,7 @@ def main():
         if "--max-iter" not in sys.argv:
             a.max_iter = 5000
         if "--instances" not in sys.argv:
-            a.instances = 1024
+            a.instances = 1536      # two full rounds of 3 workgroups per CU
     if c3:
         if "--max-iter" not in sys.argv:
             a.max_iter = 20000

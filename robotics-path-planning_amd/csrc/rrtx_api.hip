@@ -230,6 +230,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     if ((rc = dalloc(h, &d.pool_used, h->n_inst))) return rc;
     if ((rc = dalloc(h, &d.spx, (size_t)rppd::PMAX * h->n_inst))) return rc;
     if ((rc = dalloc(h, &d.spy, (size_t)rppd::PMAX * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.plans, (size_t)rppd::NUD * h->n_inst))) return rc;
     d.curvature = p->curvature;
     d.goal_yaw_th = p->goal_yaw_th;
     d.goal_xy_th = p->goal_xy_th;

@@ -48,22 +48,41 @@ int main(int argc, char** argv) {
   // Dubins: prepared plan + independent point evaluation == the oracle's sequential plan_dubins_path
   {
     static double opx[8192], opy[8192], opyaw[8192];
-    for (long i = 0; i < N / 100 + 50; i++) {
+    for (long i = 0; i < N / 20 + 50; i++) {
       double sx = u01() * 17 - 2, sy = u01() * 17 - 2, syaw = (u01() * 2 - 1) * 3.141592653589793;
       double gx = u01() * 17 - 2, gy = u01() * 17 - 2, gyaw = (u01() * 2 - 1) * 3.141592653589793;
       if (i % 6 == 0) { gx = sx + (u01() - 0.5) * 0.5; gy = sy + (u01() - 0.5) * 0.5; }
       if (i % 11 == 0) { gyaw = syaw; }
+      if (i % 13 == 0) {   // symmetric / axis-aligned poses: equal trig terms, zero differences, zero yaw
+        const double q[5] = {0.0, 1.5707963267948966, -1.5707963267948966, 3.141592653589793, 0.7853981633974483};
+        syaw = q[i % 5];
+        gyaw = (i % 2) ? syaw : q[(i / 5) % 5];
+        const double L = 1.0 + (i % 7);
+        gx = sx + L * cos(syaw);
+        gy = sy + L * sin(syaw);
+        if (i % 3 == 0) { sx = 0.0; sy = 0.0; gx = L; gy = 0.0; syaw = 0.0; gyaw = 0.0; }
+      }
+      const double curv = (i % 5 == 1) ? 0.5 : ((i % 5 == 3) ? 2.0 : 1.0);
       double ln[3]; char md[4];
-      int n = odub(sx, sy, syaw, gx, gy, gyaw, 1.0, opx, opy, opyaw, 8192, ln, md);
-      rpp::DubinsPlan P; rpp::dubins_prepare(&P, sx, sy, syaw, gx, gy, gyaw, 1.0);
+      int n = odub(sx, sy, syaw, gx, gy, gyaw, curv, opx, opy, opyaw, 8192, ln, md);
+      rpp::DubinsPlan P; rpp::dubins_prepare(&P, sx, sy, syaw, gx, gy, gyaw, curv);
       if ((P.ok ? P.total : 0) != n) { if (bad++ < 5) printf("dubins count %d vs %d\n", P.total, n); continue; }
       for (int k = 0; k < n; k++) {
-        double wx, wy, wyaw; rpp::dubins_point(P, k, 1.0, &wx, &wy, &wyaw);
+        double wx, wy, wyaw; rpp::dubins_point(P, k, curv, &wx, &wy, &wyaw);
         if (memcmp(&wx, &opx[k], 8) || memcmp(&wy, &opy[k], 8) || memcmp(&wyaw, &opyaw[k], 8)) {
           if (bad++ < 5) printf("dubins point %d/%d: (%a,%a,%a) vs (%a,%a,%a)\n", k, n, wx, wy, wyaw, opx[k], opy[k], opyaw[k]);
           break;
         }
       }
+    }
+  }
+  // symmetries rpp_dubins.h relies on: sin odd, cos even, atan2 odd in y -- bit for bit
+  for (long i = 0; i < N * 5; i++) {
+    const double a = (u01() * 2 - 1) * 7, b = (u01() * 2 - 1) * 30;
+    const double s1 = rpp_glibc_sin(-a), s2 = -rpp_glibc_sin(a), c1 = rpp_glibc_cos(-a), c2 = rpp_glibc_cos(a);
+    const double t1 = rpp_glibc_atan2(-a, b), t2 = -rpp_glibc_atan2(a, b);
+    if (memcmp(&s1, &s2, 8) || memcmp(&c1, &c2, 8) || memcmp(&t1, &t2, 8)) {
+      if (bad++ < 5) printf("symmetry %a %a\n", a, b);
     }
   }
   // hypot, **2
