@@ -39,10 +39,11 @@ def main():
                     help="planning instances per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
     ap.add_argument("--obstacles", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations (the headline metric); c3: rrt_07 Informed RRT* "
                          "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 768 instances; "
-                         "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1024 instances")
+                         "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1536 instances; "
+                         "c4: rrt_08 BIT*, driver constants, per-instance start/goal (SURVEY 8d), 80 iterations")
     ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
@@ -87,6 +88,12 @@ def main():
     import rrt_amd
     sharding = importlib.import_module("robotics-path-planning_amd.sharding")
     A = rrt_amd._abi
+    if a.workload == "c4":
+        bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     kw = util.c2_kwargs(a.max_iter, m=a.obstacles)
     if c3:
         kw = dict(algo="informed", start=[2, 2], goal=[98, 98], obstacles=util.synth_map(11, a.obstacles, 0.3, 1.5),
@@ -254,6 +261,94 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu):
+    """C4: rrt_08 BIT*, driver constants (rrt_08:633-665); instance i has start/goal drawn from
+    random.Random(2000+i) in [-1,14]^2 outside the obstacles and planner seed 1000+i; rank r owns instances
+    r*B .. (r+1)*B-1.  One step = every instance planned (maxIter 80).  Unit of work: edges popped from the edge queue."""
+    import random
+    import numpy as np
+    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+    B = a.instances if "--instances" in sys.argv else 4096
+    max_iter = a.max_iter if "--max-iter" in sys.argv else 80
+    cuda = torch.device("cuda", local_rank) if dist is not None else None
+
+    def free_point(rng):
+        while True:
+            x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
+            if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
+                return [x, y]
+    starts, goals, seeds = [], [], []
+    for i in range(rank * B, (rank + 1) * B):
+        rng = random.Random(2000 + i)
+        starts.append(free_point(rng))
+        goals.append(free_point(rng))
+        seeds.append(1000 + i)
+    c_min, c = rrt_amd.bitstar_rotation(starts[0], goals[0])
+    h = A.Handle(A.ALGO_BITSTAR, starts[0], goals[0], [-2.0, 15.0], 2.0, 1.0, 0, max_iter, n_instances=B,
+                 device=local_rank, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+    h.set_obstacles(obst)
+    h.seed_instances(seeds)
+    for i in range(B):
+        cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])   # numpy SVD on the host, as the reference does
+        h.set_instance(i, starts[i], goals[i])
+        h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+    for _ in range(a.warmup):
+        h.seed_instances(seeds)
+        h.plan()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    edges = 0
+    for _ in range(a.steps):
+        h.seed_instances(seeds)
+        h.plan()
+        s = h.get_stats()
+        kernel_ms += s["kernel_ms"]
+        edges += s["edges_unique"]
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pc, nn, st = h.get_results()
+    tmax = sharding.reduce_max(dist, dt, cuda)
+    (tot_edges,) = sharding.reduce_sum_int(dist, [edges], cuda)
+    all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda)
+    if rank == 0:
+        found = (all_st & 2) != 0
+        line = {"metric": "BIT* edge-queue expansions/sec (edges popped and processed, rrt_08:262-318), %d-iteration plans"
+                          % max_iter,
+                "value": tot_edges / tmax, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": 1e3 * tmax / max(a.steps, 1), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "C4: rrt_08 BIT*, driver constants (6 obstacles, rand_area [-2,15], maxIter %d), "
+                                       "per-instance start/goal from random.Random(2000+i), planner seed 1000+i, "
+                                       "%d instances/GPU" % (max_iter, B),
+                           "instances_per_gpu": B, "max_iter": max_iter, "parallelism": "instances x%d" % ngpu},
+                "plans_per_s": B * ngpu * a.steps / tmax, "paths_found": int(found.sum()),
+                "instances_total": int(len(all_pc)), "mean_vertices_per_tree": float(np.mean(all_nn)),
+                "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
+                             "traffic": None, "kernel": "rppb::bitstar_kernel",
+                             "note": "instance-parallel sequential search (one lane per instance): latency-bound, "
+                                     "no streaming pass to price against HBM",
+                             "kernel_ms_per_step": kernel_ms / max(a.steps, 1)}}
+        if not a.no_cpu_baseline:
+            import oracle
+            nsmp = min(B, 48)
+            tc = time.perf_counter()
+            ce = 0
+            for i in range(nsmp):
+                r = oracle.plan_bitstar(starts[i], goals[i], obst, [-2, 15], max_iter, seed=seeds[i])
+                ce += int(r.get("n_trace", 0)) if isinstance(r, dict) else 0
+            tc = time.perf_counter() - tc
+            line["cpu_baseline"] = {"value": nsmp / tc, "unit": "plans/s", "cores": 1, "kind": "port",
+                                    "sample": "oracle/rrt_oracle.c, the first %d instances of the same workload, %.1f s "
+                                              "(compare with plans_per_s)" % (nsmp, tc)}
+        print(json.dumps(line), flush=True)
+    h.close()
 
 
 if __name__ == "__main__":

@@ -38,6 +38,11 @@ struct BitState {
   int32_t *te_a, *te_b;             // tree edges (vertex indices) in add_edge order = adjacency list order
   double* vq;                       // vertex_queue
   double *eq_a, *eq_b;              // edge_queue
+  // cached with each queue entry (values the reference recomputes on every queue scan; they never change):
+  // tree index of the edge's first vertex (always a tree vertex: it comes from the vertex queue, and vertices are
+  // never removed), dist(a, b), dist(b, goal); per vertex: dist(v, goal)
+  int32_t *eq_ai, *vq_i;
+  double *eq_dab, *eq_hb, *vh;
   int32_t *open, *closed;           // update_graph work lists
   double* path;                     // result, start -> goal
   double *tr_a, *tr_b;              // optional trace of popped edges
@@ -116,6 +121,18 @@ RPP_HD static inline void bit_informed_sample(const BitCfg& c, BitState& s, RNG*
     if (!bit_dict_put(s.sid, s.sx, s.sy, &s.ns, s.scap, s.lid[i], s.lx[i], s.ly[i])) s.error = 2;
 }
 
+// edge_queue.remove at position ri (order preserving), cached columns included
+RPP_HD static inline void bit_eq_erase(BitState& s, int ri) {
+  for (int j = ri; j + 1 < s.neq; j++) {
+    s.eq_a[j] = s.eq_a[j + 1];
+    s.eq_b[j] = s.eq_b[j + 1];
+    s.eq_ai[j] = s.eq_ai[j + 1];
+    s.eq_dab[j] = s.eq_dab[j + 1];
+    s.eq_hb[j] = s.eq_hb[j + 1];
+  }
+  s.neq--;
+}
+
 RPP_HD static inline double bit_g(const BitState& s, const BitCfg& c, double id, double goal_id) {
   const int vi = bit_vfind(s, id);
   if (vi >= 0) return s.vg[vi];
@@ -136,6 +153,7 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
   s.vid[0] = start_id;
   s.vg[0] = 0.0;
   s.vf[0] = bit_dist(c, start_id, goal_id);
+  s.vh[0] = bit_dist(c, start_id, goal_id);
   s.vhasp[0] = 0;
   s.vpar[0] = -1.0;
   s.nv = 1;
@@ -163,6 +181,7 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
             s.error = 2;
             break;
           }
+          s.vq_i[s.nvq] = q;
           s.vq[s.nvq++] = s.vid[q];
         }
       }
@@ -172,7 +191,7 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
       double bv = dinf();
       int bvi = -1;
       for (int j = 0; j < s.nvq; j++) {
-        const double val = bit_g(s, c, s.vq[j], goal_id) + bit_dist(c, s.vq[j], goal_id);
+        const double val = s.vg[s.vq_i[j]] + s.vh[s.vq_i[j]];   // g(v) + h(v) :439-446
         if (val < bv) {
           bv = val;
           bvi = j;
@@ -182,8 +201,7 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
       if (s.neq) {
         be = -dinf();
         for (int j = 0; j < s.neq; j++) {   // values.sort(reverse=True)[0]: the MAXIMUM (:452-453)
-          const double val = bit_g(s, c, s.eq_a[j], goal_id) + bit_dist(c, s.eq_a[j], s.eq_b[j]) +
-                             bit_dist(c, s.eq_b[j], goal_id);
+          const double val = s.vg[s.eq_ai[j]] + s.eq_dab[j] + s.eq_hb[j];   // g(a) + c(a,b) + h(b) :448-456
           if (val > be) be = val;
         }
       }
@@ -194,14 +212,20 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
       }
       if (bvi < 0) bvi = 0;
       const double vid = s.vq[bvi];
-      for (int j = bvi; j + 1 < s.nvq; j++) s.vq[j] = s.vq[j + 1];   // vertex_queue.remove(vid)
+      const int vidx = s.vq_i[bvi];
+      for (int j = bvi; j + 1 < s.nvq; j++) {   // vertex_queue.remove(vid)
+        s.vq[j] = s.vq[j + 1];
+        s.vq_i[j] = s.vq_i[j + 1];
+      }
       s.nvq--;
+      const double d_sv = bit_dist(c, start_id, vid);
       double cx, cy;
       bit_coord(c, vid, &cx, &cy);
       for (int k = 0; k < s.ns; k++) {   // samples.items() in dict order; RAW sample coordinates (:485-488)
         if (bit_norm(s.sx[k] - cx, s.sy[k] - cy) <= 2.0 && s.sid[k] != vid) {
           const double sid = s.sid[k];
-          const double est = bit_dist(c, start_id, vid) + bit_dist(c, sid, goal_id) + bit_dist(c, vid, sid);
+          const double d_sg = bit_dist(c, sid, goal_id), d_vs = bit_dist(c, vid, sid);
+          const double est = d_sv + d_sg + d_vs;
           if (est < s.g_goal) {
             if (s.neq >= s.eqcap) {
               s.error = 2;
@@ -209,6 +233,9 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
             }
             s.eq_a[s.neq] = vid;
             s.eq_b[s.neq] = sid;
+            s.eq_ai[s.neq] = vidx;
+            s.eq_dab[s.neq] = d_vs;
+            s.eq_hb[s.neq] = d_sg;
             s.neq++;
           }
         }
@@ -222,14 +249,15 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
     int bi = 0;
     double bval = dinf();
     for (int j = 0; j < s.neq; j++) {
-      const double val =
-          bit_g(s, c, s.eq_a[j], goal_id) + bit_dist(c, s.eq_a[j], s.eq_b[j]) + bit_dist(c, s.eq_b[j], goal_id);
+      const double val = s.vg[s.eq_ai[j]] + s.eq_dab[j] + s.eq_hb[j];
       if (val < bval) {
         bval = val;
         bi = j;
       }
     }
     const double ea = s.eq_a[bi], eb = s.eq_b[bi];
+    const int ea_i = s.eq_ai[bi];
+    const double ea_dab = s.eq_dab[bi], ea_hb = s.eq_hb[bi];
     if (s.tr_a && s.tr_n < s.tr_cap) {
       s.tr_a[s.tr_n] = ea;
       s.tr_b[s.tr_n] = eb;
@@ -242,14 +270,10 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
           ri = j;
           break;
         }
-      for (int j = ri; j + 1 < s.neq; j++) {
-        s.eq_a[j] = s.eq_a[j + 1];
-        s.eq_b[j] = s.eq_b[j + 1];
-      }
-      s.neq--;
+      bit_eq_erase(s, ri);
     }
-    int v0 = bit_vfind(s, ea);
-    const double dab = bit_dist(c, ea, eb), hb = bit_dist(c, eb, goal_id);
+    const int v0 = ea_i;
+    const double dab = ea_dab, hb = ea_hb;
     const double est_v = s.vg[v0] + dab + hb;
     const double est_e = bit_dist(c, start_id, ea) + dab + hb;
     const double act_e = s.vg[v0] + dab;
@@ -312,6 +336,8 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
       s.vid[vn] = next_id;
       s.vhasp[vn] = 0;
       s.vpar[vn] = -1.0;
+      s.vh[vn] = bit_dist(c, next_id, goal_id);
+      s.vq_i[s.nvq] = vn;
       s.vq[s.nvq++] = next_id;
       if (next_id == goal_id || ea == goal_id) s.found_goal = 1;   // :300-303 (bestEdge rebound to (e0, next) :289)
       {   // tree.add_edge :62-66
@@ -387,13 +413,7 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
                   ri = j;
                   break;
                 }
-              if (ri >= 0) {
-                for (int j = ri; j + 1 < s.neq; j++) {
-                  s.eq_a[j] = s.eq_a[j + 1];
-                  s.eq_b[j] = s.eq_b[j + 1];
-                }
-                s.neq--;
-              }
+              if (ri >= 0) bit_eq_erase(s, ri);
             }
           }
         }

@@ -25,8 +25,9 @@ struct BitArgs {
   double *tr_a, *tr_b;       // optional trace of instance trace_inst
   int32_t tr_cap, trace_inst;
 };
-constexpr int64_t DSLAB = 3LL * SC + 3LL * LC + 5LL * VC + 2LL * EC + 2LL * PC;
-constexpr int64_t ISLAB = 5LL * VC;
+// (the arrays rrtx_get_tree / rrtx_get_path read back keep their offsets; the cached columns follow them)
+constexpr int64_t DSLAB = 3LL * SC + 3LL * LC + 5LL * VC + 2LL * EC + 2LL * PC + 2LL * EC + VC;
+constexpr int64_t ISLAB = 5LL * VC + EC + VC;
 
 __global__ void bitstar_kernel(BitArgs a, rppk::Inst* inst, rppk::Result* results, int n_inst) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,8 +39,10 @@ __global__ void bitstar_kernel(BitArgs a, rppk::Inst* inst, rppk::Result* result
   s.lid = d; d += LC; s.lx = d; d += LC; s.ly = d; d += LC;
   s.vid = d; d += VC; s.vg = d; d += VC; s.vf = d; d += VC; s.vpar = d; d += VC; s.vq = d; d += VC;
   s.eq_a = d; d += EC; s.eq_b = d; d += EC;
-  s.path = d;
-  s.vhasp = q; q += VC; s.te_a = q; q += VC; s.te_b = q; q += VC; s.open = q; q += VC; s.closed = q;
+  s.path = d; d += 2LL * PC;
+  s.eq_dab = d; d += EC; s.eq_hb = d; d += EC; s.vh = d;
+  s.vhasp = q; q += VC; s.te_a = q; q += VC; s.te_b = q; q += VC; s.open = q; q += VC; s.closed = q; q += VC;
+  s.eq_ai = q; q += EC; s.vq_i = q;
   s.scap = SC; s.lcap = LC; s.vcap = VC; s.tecap = VC; s.vqcap = VC; s.eqcap = EC; s.path_cap = PC;
   s.tr_a = (i == a.trace_inst) ? a.tr_a : nullptr;
   s.tr_b = (i == a.trace_inst) ? a.tr_b : nullptr;

@@ -24,11 +24,13 @@ extern "C" int host_bitstar(const double* start, const double* goal, double rand
   c.max_iter = max_iter; c.m = m; c.ox = ox.data(); c.oy = oy.data(); c.othr = othr.data();
   const int SC = 4096, LC = 512, VC = 1024, EC = 1 << 16;
   std::vector<double> sid(SC), sx(SC), sy(SC), lid(LC), lx(LC), ly(LC), vid(VC), vg(VC), vf(VC), vpar(VC), vq(VC), ea(EC), eb(EC);
-  std::vector<int32_t> vh(VC), ta(VC), tb(VC), op(VC), cl(VC);
+  std::vector<int32_t> vh(VC), ta(VC), tb(VC), op(VC), cl(VC), eai(EC), vqi(VC);
+  std::vector<double> edab(EC), ehb(EC), vhg(VC);
   rpp::BitState s; memset(&s, 0, sizeof(s));
   s.sid = sid.data(); s.sx = sx.data(); s.sy = sy.data(); s.lid = lid.data(); s.lx = lx.data(); s.ly = ly.data();
   s.vid = vid.data(); s.vg = vg.data(); s.vf = vf.data(); s.vpar = vpar.data(); s.vhasp = vh.data();
   s.te_a = ta.data(); s.te_b = tb.data(); s.vq = vq.data(); s.eq_a = ea.data(); s.eq_b = eb.data();
+  s.eq_ai = eai.data(); s.vq_i = vqi.data(); s.eq_dab = edab.data(); s.eq_hb = ehb.data(); s.vh = vhg.data();
   s.open = op.data(); s.closed = cl.data(); s.path = path; s.tr_a = tr_a; s.tr_b = tr_b;
   s.scap = SC; s.lcap = LC; s.vcap = VC; s.tecap = VC; s.vqcap = VC; s.eqcap = EC; s.path_cap = path_cap; s.tr_cap = tr_cap;
   rpp::MT rng; memcpy(rng.mt, mt624, 624 * 4); rng.pos = *pos;
