@@ -294,9 +294,18 @@ def bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu):
         cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])   # numpy SVD on the host, as the reference does
         h.set_instance(i, starts[i], goals[i])
         h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+    def plan_tolerant():
+        # an instance whose start is walled in keeps drawing sample batches without bound (the reference would too);
+        # it ends with RRTX_E_OVERFLOW in its status word and is reported below, the other instances are unaffected
+        try:
+            h.plan()
+        except A.RrtxError as e:
+            if "OVERFLOW" not in str(e):
+                raise
+
     for _ in range(a.warmup):
         h.seed_instances(seeds)
-        h.plan()
+        plan_tolerant()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
@@ -305,7 +314,7 @@ def bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu):
     edges = 0
     for _ in range(a.steps):
         h.seed_instances(seeds)
-        h.plan()
+        plan_tolerant()
         s = h.get_stats()
         kernel_ms += s["kernel_ms"]
         edges += s["edges_unique"]
@@ -329,6 +338,7 @@ def bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu):
                                        "%d instances/GPU" % (max_iter, B),
                            "instances_per_gpu": B, "max_iter": max_iter, "parallelism": "instances x%d" % ngpu},
                 "plans_per_s": B * ngpu * a.steps / tmax, "paths_found": int(found.sum()),
+                "instances_capacity_exceeded": int(((all_st & 4) != 0).sum()),
                 "instances_total": int(len(all_pc)), "mean_vertices_per_tree": float(np.mean(all_nn)),
                 "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
                              "traffic": None, "kernel": "rppb::bitstar_kernel",

@@ -10,7 +10,7 @@
 
 namespace rppb {
 
-constexpr int SC = 4096;     // samples
+constexpr int SC = 4096;     // samples (an instance that needs more ends with RRTX_ST_OVERFLOW: a walled-in start resamples without bound)
 constexpr int LC = 512;      // samples of one batch
 constexpr int VC = 1024;     // tree vertices / vertex queue / tree edges
 constexpr int EC = 32768;    // edge queue

@@ -1,0 +1,626 @@
+// rrt_bitstar_wave.hip.h -- BIT* (rrt_08) on the GPU, one wave (64 lanes) per planning instance.
+// Reference: 10_path_planning_01_rrt_08_batch_informed_rrt_star.py BITStar.plan :236-331 and everything it calls;
+// rpp_bitstar.h holds the sequential restatement (host-tested against the reference's goldens) this kernel follows
+// statement by statement.  What the reference does with Python containers per iteration is a handful of linear
+// passes -- queue "best" values = full rebuild + sort (:439-474), expand_vertex over every sample (:476-501),
+// list.remove, dict deletion, an A*-style sweep of the tree (:524-556) -- and those passes are what the lanes share:
+//   * first-minimum / maximum reductions over the vertex and edge queues (cached g/h terms, see rpp_bitstar.h);
+//   * expand_vertex as a ballot-ordered append (edges enter the queue in sample order, as the dict iteration does);
+//   * order-preserving deletion (list.remove, del dict[k]) as a chunked shift;
+//   * connect()'s point-sampled collision test (:359-383) with the first colliding point found by ballot;
+//   * update_graph with O(1) open / closed membership flags, successors enumerated in adjacency (append) order;
+//   * informed_sample: the MT19937 draws stay sequential (lane 0, stream order), coordinates / grid ids in parallel,
+//     dictionary insertion with the reference's key semantics (existing keys keep their slot, last value wins).
+// Control flow is wave-uniform: every branch depends on reduced / broadcast values only.
+// Small per-vertex state lives in LDS (max_iter + 1 <= VL vertices); samples and the edge queue in the instance's
+// global slab (lane-strided, coalesced).  Larger problems use the one-lane-per-instance kernel of rrt_bitstar.hip.h.
+#pragma once
+#include "rrt_bitstar.hip.h"
+
+namespace rppb {
+
+constexpr int VL = 128;    // vertices / vertex queue / tree edges held in LDS
+constexpr int RB = 404;    // random numbers of one informed_sample batch (2 per sample, <= 201 samples)
+constexpr int OB = 64;     // obstacles held in LDS
+
+struct ShB {
+  rpp::MT rng;
+  double vid[VL], vg[VL], vf[VL], vpar[VL], vh[VL], vq[VL];
+  int32_t vhasp[VL], vq_i[VL], te_a[VL], te_b[VL], open[VL], inopen[VL], inclosed[VL];
+  double rnd[RB];
+  double ox[OB], oy[OB], othr[OB];
+};
+
+__device__ __forceinline__ void wsync() { __syncthreads(); }   // one wave per workgroup: orders LDS / global traffic
+
+// (value, index) -> smallest value, lowest index among equals; index 0x7fffffff when no lane had a candidate
+__device__ __forceinline__ void w_argmin(double& v, int& i) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(i, o);
+    const bool take = (ov < v) || (ov == v && oi < i);
+    v = take ? ov : v;
+    i = take ? oi : i;
+  }
+}
+__device__ __forceinline__ double w_max(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ov = __shfl_xor(v, o);
+    v = ov > v ? ov : v;
+  }
+  return v;
+}
+// first j in [from, n) with a[j] == key, else -1 (wave-uniform result)
+template <class T>
+__device__ __forceinline__ int w_find(const T* a, int from, int n, T key) {
+  const int lane = threadIdx.x;
+  for (int base = from; base < n; base += 64) {
+    const int j = base + lane;
+    const uint64_t m = __ballot(j < n && a[j] == key);
+    if (m) return base + __ffsll((long long)m) - 1;
+  }
+  return -1;
+}
+__device__ __forceinline__ int w_find_pair(const double* a, const double* b, int n, double ka, double kb) {
+  const int lane = threadIdx.x;
+  for (int base = 0; base < n; base += 64) {
+    const int j = base + lane;
+    const uint64_t m = __ballot(j < n && a[j] == ka && b[j] == kb);
+    if (m) return base + __ffsll((long long)m) - 1;
+  }
+  return -1;
+}
+// list.remove at position ri of an array of length n (order preserving)
+template <class T>
+__device__ __forceinline__ void w_erase(T* a, int ri, int n) {
+  const int lane = threadIdx.x;
+  for (int base = ri; base + 1 < n; base += 256) {
+    T t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + u * 64 + lane;
+      if (j + 1 < n) t[u] = a[j + 1];
+    }
+    wsync();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + u * 64 + lane;
+      if (j + 1 < n) a[j] = t[u];
+    }
+    wsync();
+  }
+}
+
+__global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst* inst, rppk::Result* results,
+                                                          int n_inst) {
+  __shared__ ShB sh;
+  const int I = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (I >= n_inst) return;
+  const rpp::BitCfg c = a.cfg[I];
+  double* d = a.dslab + (int64_t)I * DSLAB;
+  int32_t* q = a.islab + (int64_t)I * ISLAB;
+  double* sid = d; d += SC;
+  double* sx = d; d += SC;
+  double* sy = d; d += SC;
+  double* lid = d; d += LC;   // raw batch of informed_sample: id, x, y per drawn sample
+  double* lx = d; d += LC;
+  double* ly = d; d += LC;
+  double* g_vid = d; d += VC;
+  double* g_vg = d; d += VC;
+  double* g_vf = d; d += VC;
+  double* g_vpar = d; d += VC;
+  d += VC;   // vq (LDS here)
+  double* eq_a = d; d += EC;
+  double* eq_b = d; d += EC;
+  double* path = d; d += 2LL * PC;
+  double* eq_dab = d; d += EC;
+  double* eq_hb = d; d += EC;
+  int32_t* g_vhasp = q; q += 5LL * VC;
+  int32_t* eq_ai = q;
+  double* tr_a = (I == a.trace_inst) ? a.tr_a : nullptr;
+  double* tr_b = (I == a.trace_inst) ? a.tr_b : nullptr;
+
+  for (int i = lane; i < 624; i += 64) sh.rng.mt[i] = inst[I].rng.mt[i];
+  for (int i = lane; i < c.m; i += 64) {
+    sh.ox[i] = c.ox[i];
+    sh.oy[i] = c.oy[i];
+    sh.othr[i] = c.othr[i];
+  }
+  if (lane == 0) sh.rng.pos = inst[I].rng.pos;
+  wsync();
+
+  // wave-uniform scalars
+  int ns = 0, nv = 0, nte = 0, nvq = 0, neq = 0, path_n = 0, tr_n = 0, error = 0, iterations = 0, found_goal = 0;
+  double g_goal = rpp::dinf();
+  const double inf = rpp::dinf();
+  const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+  const double start_id = rpp::bit_id(c, c.start[0], c.start[1]), goal_id = rpp::bit_id(c, c.goal[0], c.goal[1]);
+  if (lane == 0) {
+    sid[0] = goal_id;
+    sx[0] = c.goal[0];
+    sy[0] = c.goal[1];
+    sh.vid[0] = start_id;
+    sh.vg[0] = 0.0;
+    sh.vf[0] = rpp::bit_dist(c, start_id, goal_id);
+    sh.vh[0] = rpp::bit_dist(c, start_id, goal_id);
+    sh.vhasp[0] = 0;
+    sh.vpar[0] = -1.0;
+  }
+  ns = 1;
+  nv = 1;
+  wsync();
+
+  // informed_sample(m, cMax, ...) :397-420 followed by self.samples.update(...)
+  auto informed_sample = [&](int mm, double c_max) {
+    const int cnt = mm + 1;
+    if (lane == 0)
+      for (int i = 0; i < 2 * cnt; i++) sh.rnd[i] = rpp::mt_random(&sh.rng);   // stream order: a, b (or x, y) per sample
+    wsync();
+    for (int i = lane; i < cnt; i += 64) {
+      double rx, ry;
+      if (c_max < inf) {
+        const double r0 = c_max / 2.0;
+        const double r1 = __builtin_sqrt(rpp::py_sq(c_max) - c.c_min2) / 2.0;
+        double aa = sh.rnd[2 * i], bb = sh.rnd[2 * i + 1];
+        if (bb < aa) {
+          const double t = aa;
+          aa = bb;
+          bb = t;
+        }
+        const double ang = 2 * 3.141592653589793 * aa / bb;
+        const double s0 = bb * rpp_glibc_cos(ang), s1 = bb * rpp_glibc_sin(ang);
+        const double t00 = c.rot[0] * r0, t01 = c.rot[1] * r1, t10 = c.rot[2] * r0, t11 = c.rot[3] * r1;
+        rx = __builtin_fma(t00, s0, t01 * s1) + (c.start[0] + c.goal[0]) / 2.0;
+        ry = __builtin_fma(t10, s0, t11 * s1) + (c.start[1] + c.goal[1]) / 2.0;
+      } else {
+        rx = c.rand_min + (c.rand_max - c.rand_min) * sh.rnd[2 * i];       // sample_free_space :433-437
+        ry = c.rand_min + (c.rand_max - c.rand_min) * sh.rnd[2 * i + 1];
+      }
+      lid[i] = rpp::bit_id(c, rx, ry);
+      lx[i] = rx;
+      ly[i] = ry;
+    }
+    wsync();
+    for (int i = lane; i < cnt; i += 64) sh.rnd[i] = lid[i];   // ids of the batch in LDS
+    wsync();
+    // does any drawn id repeat (inside the batch or against the samples already held)?
+    int dup = 0;
+    for (int i = lane; i < cnt; i += 64) {
+      const double id = sh.rnd[i];
+      for (int j = 0; j < i; j++)
+        if (sh.rnd[j] == id) dup = 1;
+    }
+    for (int base = 0; base < ns; base += 64) {
+      const int k = base + lane;
+      if (k < ns) {
+        const double id = sid[k];
+        for (int j = 0; j < cnt; j++)
+          if (sh.rnd[j] == id) dup = 1;
+      }
+    }
+    const bool anydup = __ballot(dup) != 0ull;
+    if (!anydup) {
+      // all keys new: dict order = draw order
+      if (ns + cnt > SC) {
+        error = 2;
+        return;
+      }
+      for (int i = lane; i < cnt; i += 64) {
+        sid[ns + i] = sh.rnd[i];
+        sx[ns + i] = lx[i];
+        sy[ns + i] = ly[i];
+      }
+      ns += cnt;
+    } else {
+      // exact dict semantics, one key at a time: an existing key keeps its slot and takes the later value
+      for (int i = 0; i < cnt; i++) {
+        const double id = sh.rnd[i];
+        int pos = w_find(sid, 0, ns, id);
+        if (pos < 0) {
+          if (ns >= SC) {
+            error = 2;
+            return;
+          }
+          pos = ns++;
+          if (lane == 0) sid[pos] = id;
+        }
+        if (lane == 0) {
+          sx[pos] = lx[i];
+          sy[pos] = ly[i];
+        }
+        wsync();
+      }
+    }
+    wsync();
+  };
+
+  informed_sample(200, g_goal);
+
+  long guard = 0;
+  while (iterations < c.max_iter && error == 0) {
+    if (++guard > 4000000) {
+      error = 2;
+      break;
+    }
+    // ---- setup_sample :209-234
+    if (nvq == 0 && neq == 0) {
+      if (iterations != 0) {
+        int mm = 100;
+        if (found_goal) {
+          mm = 200;
+          if (lane == 0) {
+            sid[0] = goal_id;
+            sx[0] = c.goal[0];
+            sy[0] = c.goal[1];
+          }
+          ns = 1;
+          wsync();
+        }
+        informed_sample(mm, g_goal);
+        if (error) break;
+      }
+      // the vertex queue is empty here: it becomes the list of all tree vertices
+      for (int v = lane; v < nv; v += 64) {
+        sh.vq[v] = sh.vid[v];
+        sh.vq_i[v] = v;
+      }
+      nvq = nv;
+      wsync();
+    }
+    // ---- while best_vertex_queue_value() <= best_edge_queue_value(): expand_vertex(best_in_vertex_queue()) :249-251
+    int emin_i = 0x7fffffff;
+    bool fail = false;
+    for (;;) {
+      double bv = inf;
+      int bvi = 0x7fffffff;
+      for (int j = lane; j < nvq; j += 64) {
+        const int vi = sh.vq_i[j];
+        const double val = sh.vg[vi] + sh.vh[vi];
+        if (val < bv) {
+          bv = val;
+          bvi = j;
+        }
+      }
+      w_argmin(bv, bvi);
+      double be = inf;
+      emin_i = 0x7fffffff;
+      if (neq) {
+        double mx = -inf, mn = inf;
+        int mi = 0x7fffffff;
+        for (int j = lane; j < neq; j += 64) {
+          const double val = sh.vg[eq_ai[j]] + eq_dab[j] + eq_hb[j];
+          mx = val > mx ? val : mx;   // values.sort(reverse=True)[0]: the MAXIMUM (:452-453)
+          if (val < mn) {
+            mn = val;
+            mi = j;
+          }
+        }
+        be = w_max(mx);
+        w_argmin(mn, mi);
+        emin_i = mi;
+      }
+      if (!(bv <= be)) break;
+      if (nvq == 0) {
+        error = 1;   // IndexError in best_in_vertex_queue
+        fail = true;
+        break;
+      }
+      if (bvi == 0x7fffffff) bvi = 0;
+      const double vid = sh.vq[bvi];
+      const int vidx = sh.vq_i[bvi];
+      wsync();
+      w_erase(sh.vq, bvi, nvq);     // vertex_queue.remove(vid)
+      w_erase(sh.vq_i, bvi, nvq);
+      nvq--;
+      const double d_sv = rpp::bit_dist(c, start_id, vid);
+      double cx, cy;
+      rpp::bit_coord(c, vid, &cx, &cy);
+      for (int base = 0; base < ns; base += 64) {   // samples.items() in dict order; RAW sample coordinates (:485-488)
+        const int k = base + lane;
+        bool pred = false;
+        double sidk = 0.0, d_sg = 0.0, d_vs = 0.0;
+        if (k < ns) {
+          sidk = sid[k];
+          if (rpp::bit_norm(sx[k] - cx, sy[k] - cy) <= 2.0 && sidk != vid) {
+            d_sg = rpp::bit_dist(c, sidk, goal_id);
+            d_vs = rpp::bit_dist(c, vid, sidk);
+            const double est = d_sv + d_sg + d_vs;
+            pred = est < g_goal;
+          }
+        }
+        const uint64_t m = __ballot(pred);
+        if (m) {
+          const int add = __popcll(m);
+          if (neq + add > EC) {
+            error = 2;
+            fail = true;
+            break;
+          }
+          if (pred) {
+            const int pos = neq + __popcll(m & below);
+            eq_a[pos] = vid;
+            eq_b[pos] = sidk;
+            eq_ai[pos] = vidx;
+            eq_dab[pos] = d_vs;
+            eq_hb[pos] = d_sg;
+          }
+          neq += add;
+        }
+      }
+      wsync();
+      if (fail) break;
+    }
+    if (fail) break;
+    // ---- bestEdge = best_in_edge_queue(); edge_queue.remove(bestEdge) :253-255
+    if (neq == 0) {
+      error = 1;
+      break;
+    }
+    const int bi = (emin_i == 0x7fffffff) ? 0 : emin_i;
+    const double ea = eq_a[bi], eb = eq_b[bi];
+    const int ea_i = eq_ai[bi];
+    const double dab = eq_dab[bi], hb = eq_hb[bi];
+    if (tr_a && tr_n < a.tr_cap && lane == 0) {
+      tr_a[tr_n] = ea;
+      tr_b[tr_n] = eb;
+    }
+    tr_n++;
+    {
+      int ri = w_find_pair(eq_a, eq_b, neq, ea, eb);
+      if (ri < 0) ri = 0;
+      wsync();
+      w_erase(eq_a, ri, neq);
+      w_erase(eq_b, ri, neq);
+      w_erase(eq_ai, ri, neq);
+      w_erase(eq_dab, ri, neq);
+      w_erase(eq_hb, ri, neq);
+      neq--;
+    }
+    const int v0 = ea_i;
+    const double est_v = sh.vg[v0] + dab + hb;
+    const double est_e = rpp::bit_dist(c, start_id, ea) + dab + hb;
+    const double act_e = sh.vg[v0] + dab;
+    if (est_v < g_goal && est_e < g_goal && act_e < g_goal) {   // f1 and f2 and f3 :270-273
+      double fx, fy, tx, ty;
+      rpp::bit_coord(c, ea, &fx, &fy);
+      rpp::bit_coord(c, eb, &tx, &ty);
+      // connect :359-374
+      const int steps = (int)(rpp::bit_dist(c, rpp::bit_id(c, fx, fy), rpp::bit_id(c, tx, ty)) * 10);
+      const double last_edge = rpp::bit_id(c, tx, ty);
+      const double stepx = steps > 1 ? (tx - fx) / (steps - 1) : 0.0, stepy = steps > 1 ? (ty - fy) / (steps - 1) : 0.0;
+      auto point = [&](int i, double* px, double* py) {
+        if (steps > 1 && i == steps - 1) {
+          *px = tx;
+          *py = ty;
+        } else {
+          *px = (stepx == 0.0 && steps > 1) ? ((double)i / (steps - 1)) * (tx - fx) + fx : i * stepx + fx;
+          *py = (stepy == 0.0 && steps > 1) ? ((double)i / (steps - 1)) * (ty - fy) + fy : i * stepy + fy;
+        }
+      };
+      int npth = steps > 0 ? steps : 0;
+      for (int base = 0; base < steps; base += 64) {
+        const int i = base + lane;
+        bool col = false;
+        if (i < steps) {
+          double px, py;
+          point(i, &px, &py);
+          for (int k = 0; k < c.m; k++) {
+            const double dx = sh.ox[k] - px, dy = sh.oy[k] - py;
+            if (dx * dx + dy * dy <= sh.othr[k]) col = true;
+          }
+        }
+        const uint64_t m = __ballot(col);
+        if (m) {
+          npth = base + __ffsll((long long)m) - 1;
+          break;
+        }
+      }
+      if (npth == 0) continue;   // path None or empty: no iteration count (:283-284)
+      double lx2, ly2;
+      point(npth - 1, &lx2, &ly2);
+      const double next_id = rpp::bit_id(c, lx2, ly2);
+      if (w_find(sh.vid, 0, nv, next_id) >= 0) continue;   // :291-292
+      {   // del self.samples[next_id]
+        const int di = w_find(sid, 0, ns, next_id);
+        if (di >= 0) {
+          wsync();
+          w_erase(sid, di, ns);
+          w_erase(sx, di, ns);
+          w_erase(sy, di, ns);
+          ns--;
+        }
+      }
+      if (nv >= VL || nvq >= VL || nte >= VL) {
+        error = 2;
+        break;
+      }
+      const int vn = nv++;
+      const double gs = rpp::bit_dist(c, ea, next_id);
+      if (lane == 0) {
+        sh.vid[vn] = next_id;
+        sh.vhasp[vn] = 0;
+        sh.vpar[vn] = -1.0;
+        sh.vh[vn] = rpp::bit_dist(c, next_id, goal_id);
+        sh.vq_i[nvq] = vn;
+        sh.vq[nvq] = next_id;
+        sh.te_a[nte] = v0;   // tree.add_edge :62-66
+        sh.te_b[nte] = vn;
+        sh.vg[vn] = gs + sh.vg[v0];
+        sh.vf[vn] = gs + rpp::bit_dist(c, next_id, goal_id);
+      }
+      nvq++;
+      nte++;
+      if (next_id == goal_id || ea == goal_id) found_goal = 1;   // :300-303 (bestEdge rebound to (e0, next) :289)
+      wsync();
+      if (next_id == goal_id) g_goal = sh.vg[vn];
+      // ---- update_graph :524-556
+      {
+        for (int v = lane; v < nv; v += 64) {
+          sh.inopen[v] = 0;
+          sh.inclosed[v] = 0;
+        }
+        if (lane == 0) {
+          sh.open[0] = 0;
+        }
+        wsync();
+        if (lane == 0) sh.inopen[0] = 1;
+        int no = 1;
+        wsync();
+        while (no) {
+          double mv = inf;
+          int mj = 0x7fffffff;
+          for (int j = lane; j < no; j += 64) {
+            const double val = sh.vf[sh.open[j]];
+            if (val < mv) {
+              mv = val;
+              mj = j;
+            }
+          }
+          w_argmin(mv, mj);   // min(openSet, key=f): first minimum
+          const int bj = (mj == 0x7fffffff) ? 0 : mj;
+          const int cur = sh.open[bj];
+          wsync();
+          w_erase(sh.open, bj, no);
+          no--;
+          if (lane == 0) sh.inopen[cur] = 0;
+          wsync();
+          const double cur_id = sh.vid[cur];
+          if (cur_id == goal_id) break;
+          if (lane == 0) sh.inclosed[cur] = 1;
+          wsync();
+          for (int base = 0; base < nte; base += 64) {   // tree.vertices[cur] in append order
+            const int e = base + lane;
+            uint64_t m = __ballot(e < nte && (sh.te_a[e] == cur || sh.te_b[e] == cur));
+            while (m) {
+              const int e2 = base + __ffsll((long long)m) - 1;
+              m &= m - 1;
+              const int su = (sh.te_a[e2] == cur) ? sh.te_b[e2] : sh.te_a[e2];
+              if (sh.inclosed[su]) continue;
+              const double su_id = sh.vid[su];
+              const double gsc = sh.vg[cur] + rpp::bit_dist(c, cur_id, su_id);
+              if (!sh.inopen[su]) {
+                if (lane == 0) {
+                  sh.open[no] = su;
+                  sh.inopen[su] = 1;
+                }
+                no++;
+              } else if (gsc >= sh.vg[su]) {
+                continue;
+              }
+              wsync();
+              if (lane == 0) {
+                sh.vg[su] = gsc;
+                sh.vf[su] = gsc + rpp::bit_dist(c, su_id, goal_id);
+                sh.vpar[su] = cur_id;
+                sh.vhasp[su] = 1;
+              }
+              if (su_id == goal_id) g_goal = gsc;
+              wsync();
+            }
+          }
+        }
+      }
+      // ---- remove_queue(lastEdge, bestEdge) :349-357 (iterates the list it mutates)
+      if (sh.vg[vn] + 0.0 >= g_goal) {
+        int i = 0;
+        for (;;) {
+          const int p = w_find(eq_b, i, neq, next_id);
+          if (p < 0) break;
+          i = p + 1;
+          const int ri = w_find_pair(eq_a, eq_b, neq, last_edge, next_id);
+          if (ri >= 0) {
+            wsync();
+            w_erase(eq_a, ri, neq);
+            w_erase(eq_b, ri, neq);
+            w_erase(eq_ai, ri, neq);
+            w_erase(eq_dab, ri, neq);
+            w_erase(eq_hb, ri, neq);
+            neq--;
+          }
+        }
+      }
+    } else {   // "Nothing good" :322-325
+      neq = 0;
+      nvq = 0;
+    }
+    iterations++;
+  }
+
+  // ---- find_final_path :333-347
+  if (!error) {
+    int np = 0;
+    bool ok = true;
+    auto push = [&](double x0, double x1) {
+      if (np < PC && lane == 0) {
+        path[2 * np] = x0;
+        path[2 * np + 1] = x1;
+      }
+      np++;
+    };
+    push(c.goal[0], c.goal[1]);
+    double cur = goal_id;
+    int hops = 0;
+    while (cur != start_id) {
+      double cx, cy;
+      rpp::bit_coord(c, cur, &cx, &cy);
+      push(cx, cy);
+      const int vi = w_find(sh.vid, 0, nv, cur);
+      if (vi < 0 || !sh.vhasp[vi] || ++hops > VC + 2) {
+        ok = false;   // KeyError: "cannot find Path" -> []
+        break;
+      }
+      cur = sh.vpar[vi];
+    }
+    if (ok) {
+      push(c.start[0], c.start[1]);
+      if (np > PC) {
+        error = 2;
+      } else {
+        wsync();
+        if (lane == 0) {
+          for (int i = 0; i < np / 2; i++) {   // plan[::-1]
+            const int j = np - 1 - i;
+            const double t0 = path[2 * i], t1 = path[2 * i + 1];
+            path[2 * i] = path[2 * j];
+            path[2 * i + 1] = path[2 * j + 1];
+            path[2 * j] = t0;
+            path[2 * j + 1] = t1;
+          }
+        }
+        path_n = np;
+      }
+    }
+  }
+  wsync();
+  // ---- results: tree columns back to the slab (rrtx_get_tree reads them), counters, RNG state
+  for (int v = lane; v < nv; v += 64) {
+    g_vid[v] = sh.vid[v];
+    g_vg[v] = sh.vg[v];
+    g_vf[v] = sh.vf[v];
+    g_vpar[v] = sh.vpar[v];
+    g_vhasp[v] = sh.vhasp[v];
+  }
+  for (int i = lane; i < 624; i += 64) inst[I].rng.mt[i] = sh.rng.mt[i];
+  if (lane == 0) {
+    inst[I].rng.pos = sh.rng.pos;
+    int32_t* o = a.out_i + 8 * I;
+    o[0] = nv; o[1] = nte; o[2] = ns; o[3] = path_n; o[4] = error; o[5] = iterations; o[6] = tr_n;
+    o[7] = found_goal;
+    a.out_g[I] = g_goal;
+    inst[I].n = nv;
+    inst[I].it = iterations;
+    inst[I].iterations = iterations;
+    inst[I].edges_unique = tr_n;
+    inst[I].edges_ref = tr_n;
+    inst[I].status = 1 | (path_n > 0 ? 2 : 0) | (error == 2 ? 4 : 0);
+    results[I].path_cost = g_goal;
+    results[I].n_nodes = nv;
+    results[I].status = inst[I].status;
+  }
+}
+
+}  // namespace rppb

@@ -18,6 +18,7 @@
 #include "rrt_informed.hip.h"
 #include "rrt_dubins.hip.h"
 #include "rrt_bitstar.hip.h"
+#include "rrt_bitstar_wave.hip.h"
 
 using rppk::Ctx;
 using rppk::Inst;
@@ -382,7 +383,13 @@ int rrtx_plan(rrtx_handle* h) {
     }
     h->ba.trace_inst = h->trace_inst;
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(rppb::bitstar_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->ba, c.inst, c.results, B);
+    // one wave per instance when the per-vertex state fits LDS (rrt_bitstar_wave.hip.h); else one lane per instance
+    const char* bk = getenv("RRTX_BITSTAR");
+    const bool wave = c.m <= rppb::OB && c.max_iter + 2 <= rppb::VL && !(bk && !strcmp(bk, "lane"));
+    if (wave)
+      hipLaunchKernelGGL(rppb::bitstar_wave_kernel, dim3(B), dim3(64), 0, h->stream, h->ba, c.inst, c.results, B);
+    else
+      hipLaunchKernelGGL(rppb::bitstar_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->ba, c.inst, c.results, B);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev1, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -515,7 +522,7 @@ int rrtx_plan(rrtx_handle* h) {
   s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   h->planned = true;
   if (overflow) {
-    h->err = "near-candidate list exceeded its on-device capacity (NU_MAX)";
+    h->err = "a fixed on-device capacity was exceeded (near-candidate list NU_MAX, polyline pool, or a BIT* slab)";
     return RRTX_E_OVERFLOW;
   }
   return RRTX_OK;

@@ -310,11 +310,15 @@ def test_gpu_bitstar_matches_reference_golden(gpu, path):
     assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
 
 
-def test_gpu_bitstar_batch_c4_style_equals_oracle(gpu):
+@pytest.mark.parametrize("kernel,n", [("wave", 160), ("lane", 12)])
+def test_gpu_bitstar_batch_c4_style_equals_oracle(gpu, monkeypatch, kernel, n):
     """C4-style batch: per-instance start/goal from random.Random(2000+i) in [-1,14]^2 outside the
-    obstacles, planner seed 1000+i; every instance equals the oracle's run."""
+    obstacles, planner seed 1000+i; every instance equals the oracle's run.  Both device kernels: one wave per
+    instance (default) and one lane per instance (the fallback for problems whose vertex state exceeds LDS)."""
     import random
     import oracle
+    if kernel == "lane":
+        monkeypatch.setenv("RRTX_BITSTAR", "lane")
     obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
 
     def free_point(rng):
@@ -322,7 +326,6 @@ def test_gpu_bitstar_batch_c4_style_equals_oracle(gpu):
             x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
             if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
                 return [x, y]
-    n = 24
     starts, goals, seeds = [], [], []
     for i in range(n):
         rng = random.Random(2000 + i)
