@@ -123,6 +123,37 @@ def test_gpu_c2_20k_nodes_equals_oracle(gpu):
         assert np.array_equal(out["paths"][i], r["path"])
 
 
+def test_gpu_c2_full_size_equals_oracle(gpu):
+    """BASELINE.json's full size (C2: 105 000 iterations, ~101 k nodes): the product kernel (f32-mirror pass) against
+    the golden-pinned oracle, bit for bit -- tree, path, counters.  ~2 min of oracle time on one host core."""
+    kw = util.c2_kwargs(105000)
+    out = util.run_gpu_batch(kw, [1])
+    r = util.run_oracle(kw, 1, exact_pow=False)
+    util.assert_tree_equal(out["trees"][0], (r["x"], r["y"], r["cost"], r["parent"]), "seed 1, 105k")
+    assert np.array_equal(out["paths"][0], r["path"])
+    for k in ("edges_ref", "edges_unique", "near_hits", "near_unique", "rewires", "propagated", "iterations"):
+        assert out["stats"][k] == r["stats"][k], k
+
+
+def test_gpu_c2_full_size_kernel_variants_agree(gpu, monkeypatch):
+    """Full size, every code path of the RRT* iteration kernel: three workgroup shapes x {f32-mirror pass, f64 pass}
+    must produce identical trees (different reductions, filters and fallbacks, one reference semantics)."""
+    kw = util.c2_kwargs(105000)
+    seeds = [2, 3, 4]
+    base = None
+    for tpb, f32 in (("256", "0"), ("256", "1"), ("128", "1"), ("64", "1"), ("64", "0")):
+        monkeypatch.setenv("RRTX_TPB", tpb)
+        monkeypatch.setenv("RRTX_F32", f32)
+        out = util.run_gpu_batch(kw, seeds)
+        sig = [tuple(np.ascontiguousarray(a).tobytes() for a in t) for t in out["trees"]]
+        paths = [None if p is None else np.asarray(p).tobytes() for p in out["paths"]]
+        if base is None:
+            base = (sig, paths, out["stats"]["rewires"], out["stats"]["propagated"])
+        else:
+            assert sig == base[0] and paths == base[1], (tpb, f32)
+            assert (out["stats"]["rewires"], out["stats"]["propagated"]) == base[2:], (tpb, f32)
+
+
 def test_size_independent_invariants(gpu):
     """Properties that hold at any size: tree consistency after planning."""
     kw = util.c2_kwargs(6000)
