@@ -41,7 +41,9 @@ enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
        RRTX_ALGO_RRT_STAR = 1,  /* rrt_04 RRT.planning :1036-1084 */
        RRTX_ALGO_INFORMED = 2,  /* rrt_07 RRT.informed_rrt_star_search :1044-1108 */
        RRTX_ALGO_DUBINS = 3,    /* rrt_05 RRT.planning :1416-1456 (RRT*-Dubins; start[2]/goal[2] = yaw) */
-       RRTX_ALGO_BITSTAR = 4    /* rrt_08 BITStar.plan :236-331 (max_iter = maxIter; rand_area = randArea) */ };
+       RRTX_ALGO_BITSTAR = 4,   /* rrt_08 BITStar.plan :236-331 (max_iter = maxIter; rand_area = randArea) */
+       RRTX_ALGO_RRT_DUBINS = 5 /* rrt_03 RRT.planning :1420-1456 (RRT with Dubins steer; poses, curvature and goal
+                                   thresholds as RRTX_ALGO_DUBINS; sampler SOBOL = the 3-D point of :1545-1563) */ };
 enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
        RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
 
@@ -72,7 +74,7 @@ typedef struct rrtx_params {
    * c_min = math.hypot(start - goal) (rrt_07:1054); the host computes both exactly as the reference does. */
   double informed_rot[4];
   double informed_c_min;
-  /* RRTX_ALGO_DUBINS only (rrt_05:1371-1373, 1411-1413) */
+  /* RRTX_ALGO_DUBINS / RRTX_ALGO_RRT_DUBINS only (rrt_05:1371-1373, 1411-1413; rrt_03:1381-1383, 1416-1418) */
   double curvature, goal_yaw_th, goal_xy_th;
 } rrtx_params;
 

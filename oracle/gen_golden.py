@@ -365,6 +365,62 @@ def main05(only=""):
     print("dubins_kat: 400 cases", flush=True)
 
 
+# ------------------------------------------------------------------------------------------------ rrt_03
+def run_rrt03(mod, name, obstacles, start, goal, rand_area, max_iter, seed, sobol, curvature=1.0, robot_radius=0.6,
+              goal_sample_rate=10):
+    """RRT with Dubins steer (rrt_03:1348-1700), driver-style call planning(animation=False)."""
+    ref_loader.reset_sobol(mod)
+    random.seed(seed)
+    rrt = mod.RRT(start=start, goal=goal, obstacle_list=obstacles, rand_area=rand_area,
+                  goal_sample_rate=goal_sample_rate, max_iter=max_iter, play_area=None, robot_radius=robot_radius,
+                  sobol_sampler=bool(sobol), curvature=curvature, goal_yaw_th=np.deg2rad(1.0), goal_xy_th=0.5)
+    tr = {"rx": [], "ry": [], "ryaw": [], "nearest": []}
+    o_near = mod.RRT.get_nearest_node_index
+
+    def near_hook(node_list, rnd):
+        i = o_near(node_list, rnd)
+        tr["rx"].append(float(rnd.x)); tr["ry"].append(float(rnd.y)); tr["ryaw"].append(float(rnd.yaw))
+        tr["nearest"].append(i)
+        return i
+    rrt.get_nearest_node_index = near_hook
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = rrt.planning(animation=False)
+    dt = time.time() - t0
+    nl = rrt.node_list
+    x, y, cost, parent = tree_arrays(nl)
+    yaw = np.array([float(nd.yaw) for nd in nl])
+    plen = np.array([len(nd.path_x) for nd in nl], dtype=np.int32)
+    ppx = np.concatenate([np.asarray(nd.path_x, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
+    ppy = np.concatenate([np.asarray(nd.path_y, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
+    state = random.getstate()
+    out = dict(algo="rrt_dubins", seed=seed, sobol=int(bool(sobol)), obstacles=np.array(obstacles, dtype=np.float64),
+               start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
+               rand_area=np.array(rand_area, dtype=np.float64), max_iter=max_iter, curvature=curvature,
+               robot_radius=robot_radius, goal_sample_rate=goal_sample_rate, goal_yaw_th=float(np.deg2rad(1.0)),
+               goal_xy_th=0.5, x=x, y=y, yaw=yaw, cost=cost, parent=parent, poly_len=plen, poly_x=ppx, poly_y=ppy,
+               path=np.array(path if path is not None else [], dtype=np.float64).reshape(-1, 2),
+               path_found=int(path is not None), ref_seconds=dt, sobol_index_after=int(rrt.sobol_inter_),
+               rng_pos_after=state[1][624], rng_word0_after=np.uint32(state[1][0]),
+               tr_rx=np.array(tr["rx"]), tr_ry=np.array(tr["ry"]), tr_ryaw=np.array(tr["ryaw"]),
+               tr_nearest=np.array(tr["nearest"], dtype=np.int32))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-28s nodes=%d path=%s maxcost=%r  %.2fs" % (name, len(x), None if path is None else len(path),
+                                                        float(cost.max()), dt), flush=True)
+
+
+def main03(only=""):
+    m03 = ref_loader.load("rrt_03")
+    obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)]       # rrt_03 driver
+    drv = dict(obstacles=obst, start=[0.0, 0.0, float(np.deg2rad(0.0))], goal=[10.0, 10.0, float(np.deg2rad(0.0))],
+               rand_area=[-2, 15])
+    for seed, it, sob in ((42, 200, 1), (1, 200, 1), (2, 400, 1), (3, 1000, 1), (42, 200, 0), (5, 600, 0), (9, 1500, 0),
+                          (11, 3000, 1)):
+        n = "rrt03_drv_s%d_it%d_%s" % (seed, it, "sobol" if sob else "mt")
+        if n.startswith(only):
+            run_rrt03(m03, n, max_iter=it, seed=seed, sobol=sob, **drv)
+
+
 def math_pi():
     import math
     return math.pi

@@ -204,16 +204,32 @@ def dubins(sx, sy, syaw, gx, gy, gyaw, curvature=1.0, cap=4096):
     return px[:n].copy(), py[:n].copy(), pyaw[:n].copy(), mode.value.decode(), ln
 
 
+def plan_rrt_dubins(start, goal, obstacles, rand_area, max_iter=200, seed=None, rng=None, curvature=1.0,
+                    robot_radius=0.0, goal_sample_rate=10, goal_yaw_th=None, goal_xy_th=0.5, sobol=False, play_area=None,
+                    trace=False):
+    """One RRT.planning(animation=False) call of rrt_03 (RRT with Dubins steer) on the oracle."""
+    return plan_dubins(start, goal, obstacles, rand_area, max_iter, seed=seed, rng=rng, curvature=curvature,
+                       robot_radius=robot_radius, goal_sample_rate=goal_sample_rate, goal_yaw_th=goal_yaw_th,
+                       goal_xy_th=goal_xy_th, trace=trace, _plain=True, _sobol=sobol, _play_area=play_area)
+
+
 def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=None, curvature=1.0, robot_radius=0.0,
                 goal_sample_rate=10, expand_dis=3.0, connect_circle_dist=50.0, goal_yaw_th=None, goal_xy_th=0.5,
-                trace=False):
+                trace=False, _plain=False, _sobol=False, _play_area=None):
     """One RRT.planning(animation=False) call of rrt_05 (RRT*-Dubins) on the oracle."""
     L = lib()
     L.orc_plan_dubins.restype = C.c_int
     L.orc_plan_dubins.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_plan_rrt_dubins.restype = C.c_int
+    L.orc_plan_rrt_dubins.argtypes = L.orc_plan_dubins.argtypes + [C.c_void_p]
     p = Params()
     p.algo = 3
+    p.sobol = int(bool(_sobol))
+    if _play_area is not None:
+        p.has_play_area = 1
+        for k in range(4):
+            p.play_area[k] = float(_play_area[k])
     p.goal_sample_rate, p.max_iter = int(goal_sample_rate), int(max_iter)
     p.start[0], p.start[1] = float(start[0]), float(start[1])
     p.goal[0], p.goal[1] = float(goal[0]), float(goal[1])
@@ -243,15 +259,21 @@ def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=
                                                                   trn.ctypes.data, trk.ctypes.data)
         o.tr_cap = int(max_iter)
     st = Stats()
-    rc = L.orc_plan_dubins(C.byref(p), float(start[2]), float(goal[2]), float(curvature), float(goal_yaw_th),
-                           float(goal_xy_th), obst.ctypes.data, len(obst), C.byref(rng), C.byref(o), C.byref(st))
+    sob_idx = C.c_int64(0)
+    if _plain:
+        rc = L.orc_plan_rrt_dubins(C.byref(p), float(start[2]), float(goal[2]), float(curvature), float(goal_yaw_th),
+                                   float(goal_xy_th), obst.ctypes.data, len(obst), C.byref(rng), C.byref(o),
+                                   C.byref(st), C.byref(sob_idx))
+    else:
+        rc = L.orc_plan_dubins(C.byref(p), float(start[2]), float(goal[2]), float(curvature), float(goal_yaw_th),
+                               float(goal_xy_th), obst.ctypes.data, len(obst), C.byref(rng), C.byref(o), C.byref(st))
     if rc != 0:
         raise RuntimeError("orc_plan_dubins failed: %d" % rc)
     n = o.n
     res = dict(x=x[:n].copy(), y=y[:n].copy(), yaw=yaw[:n].copy(), cost=cost[:n].copy(), parent=parent[:n].copy(),
                poly_len=plen[:n].copy(), poly_x=ppx[:o.poly_n].copy(), poly_y=ppy[:o.poly_n].copy(),
                path=path[:o.path_n].copy() if o.path_n else None,
-               stats={k: getattr(st, k) for k, _ in Stats._fields_}, rng=rng)
+               stats={k: getattr(st, k) for k, _ in Stats._fields_}, rng=rng, sobol_index=int(sob_idx.value))
     if trace:
         t = o.tr_n
         res.update(tr_rx=trx[:t].copy(), tr_ry=try_[:t].copy(), tr_ryaw=tryaw[:t].copy(), tr_nearest=trn[:t].copy(),

@@ -20,6 +20,7 @@ REF_DIR = "/root/reference/src_path_planning"
 FILES = {
     "rrt_01": "10_path_planning_01_rrt_01_simple.py",
     "rrt_02": "10_path_planning_01_rrt_02_sobol_sampler.py",
+    "rrt_03": "10_path_planning_01_rrt_03_dubins_path.py",
     "rrt_04": "10_path_planning_01_rrt_04_rrt_star.py",
     "rrt_05": "10_path_planning_01_rrt_05_rrt_star_dubins_path.py",
     "rrt_07": "10_path_planning_01_rrt_07_informed_rrt_star.py",
@@ -36,13 +37,18 @@ def load(short):
     src = open(path).read()
     tree = ast.parse(src, filename=path)
     body = []
+    deferred = []
     for node in tree.body:
         if isinstance(node, (ast.Import, ast.ImportFrom, ast.FunctionDef, ast.ClassDef)):
             body.append(node)
         elif isinstance(node, ast.Assign):
             names = [t.id for t in node.targets if isinstance(t, ast.Name)]
             if names and all(n in KEEP_ASSIGN for n in names):
-                body.append(node)
+                # rrt_03 builds _PATH_TYPE_MAP (:1030) BEFORE the word functions it names are defined (:1138-1218),
+                # so the script as shipped stops with NameError; the table is evaluated after the definitions here
+                # (as rrt_05:1797 places it), nothing else is reordered
+                (deferred if "_PATH_TYPE_MAP" in names else body).append(node)
+    body.extend(deferred)
     mod = types.ModuleType("ref_" + short)
     mod.__file__ = path
     code = compile(ast.Module(body=body, type_ignores=[]), path, "exec")

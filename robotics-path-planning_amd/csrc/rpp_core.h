@@ -118,14 +118,44 @@ static inline void mt_seed_u64(MT* s, uint64_t seed) {
 // 2^(30-j) (:433-436); quasi = lastq * 2^-30 (:440, :496); Gray-code step with
 // the position of the lowest zero bit of the index (:123-190, :456, :497).
 struct Sobol {
-  uint32_t lastq[2];
+  uint32_t lastq[3];
+  uint32_t pad_;
   int64_t index;
 };
 RPP_HD static inline uint32_t sobol_v(int dim, int col) {  // col = 0..29
   if (dim == 0) return 1u << (29 - col);
+  if (dim == 2) {   // third coordinate (rrt_03's i4_sobol(3, .)): poly 7, v = 1, 1, then v[j-2] ^ 2 v[j-1] ^ 4 v[j-2]
+    uint32_t a = 1, b = 1;   // v[col-2], v[col-1] while stepping
+    if (col < 2) return 1u << (29 - col);
+    uint32_t v = 0;
+    for (int j = 2; j <= col; j++) {
+      v = a ^ (2u * b) ^ (4u * a);
+      a = b;
+      b = v;
+    }
+    return v << (29 - col);
+  }
   uint32_t raw = 1;
   for (int j = 1; j <= col; j++) raw = raw ^ (2u * raw);
   return raw << (29 - col);
+}
+// i4_sobol(3, seed) with seed = 0, 1, 2, ... (rrt_03:1547)
+RPP_HD static inline void sobol_next3(Sobol* s, double q[3]) {
+  int l = 1;
+  if (s->index == 0) {
+    s->lastq[0] = s->lastq[1] = s->lastq[2] = 0;
+  } else {
+    int64_t n = s->index;
+    while (n & 1) {
+      n >>= 1;
+      l++;
+    }
+  }
+  for (int i = 0; i < 3; i++) {
+    q[i] = (double)s->lastq[i] * (1.0 / 1073741824.0);
+    s->lastq[i] ^= sobol_v(i, l - 1);
+  }
+  s->index++;
 }
 RPP_HD static inline void sobol_next(Sobol* s, double q[2]) {
   int l = 1;

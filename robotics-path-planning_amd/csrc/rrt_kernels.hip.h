@@ -1173,7 +1173,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   I->goal_node = -1;
   I->path_n = 0;
   I->sobol.index = 0;
-  I->sobol.lastq[0] = I->sobol.lastq[1] = 0;
+  I->sobol.lastq[0] = I->sobol.lastq[1] = I->sobol.lastq[2] = 0;
   I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
   I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = I->alg_bytes2 = 0;
   I->nu_max = I->f32_fallbacks = 0;

@@ -107,11 +107,13 @@ void rrtx_destroy(rrtx_handle* h) {
   delete h;
 }
 
+static inline bool is_dubins(int algo) { return algo == RRTX_ALGO_DUBINS || algo == RRTX_ALGO_RRT_DUBINS; }
+
 int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if (!p || !out) return RRTX_E_INVALID;
   *out = nullptr;
   if (p->abi_version != RRTX_ABI_VERSION) return RRTX_E_INVALID;
-  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS && p->algo != RRTX_ALGO_BITSTAR) return RRTX_E_INVALID;
+  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS && p->algo != RRTX_ALGO_BITSTAR && p->algo != RRTX_ALGO_RRT_DUBINS) return RRTX_E_INVALID;
   if (p->n_instances < 1 || p->max_iter < 0 || !(p->path_resolution > 0.0) || !(p->expand_dis >= 0.0))
     return RRTX_E_INVALID;
   int ndev = 0;
@@ -220,8 +222,9 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     }
   }
   memset(&h->da, 0, sizeof(h->da));
-  if (p->algo == RRTX_ALGO_DUBINS) {
+  if (is_dubins(p->algo)) {
     rppd::DubArgs& d = h->da;
+    d.plain = p->algo == RRTX_ALGO_RRT_DUBINS;
     d.pool_cap = 128 * cap + 4096;   // polyline points per instance (edges replaced by rewire stay allocated)
     if ((rc = dalloc(h, &d.yaw, tot))) return rc;
     if ((rc = dalloc(h, &d.poff, tot))) return rc;
@@ -456,7 +459,7 @@ int rrtx_plan(rrtx_handle* h) {
     std::vector<double> inf(B, INFINITY);
     HIPCHK(h, hipMemcpy(h->cbest, inf.data(), sizeof(double) * B, hipMemcpyHostToDevice));
   }
-  if (c.algo == RRTX_ALGO_DUBINS) HIPCHK(h, hipMemset(h->da.pool_used, 0, sizeof(int64_t) * B));
+  if (is_dubins(c.algo)) HIPCHK(h, hipMemset(h->da.pool_used, 0, sizeof(int64_t) * B));
   rppi::InformedArgs ia;
   for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
   ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
@@ -467,7 +470,7 @@ int rrtx_plan(rrtx_handle* h) {
     if (c.algo == RRTX_ALGO_INFORMED)
       hipLaunchKernelGGL(rppi::rrt_informed_kernel, dim3(B), dim3(rppi::TPB), 0, h->stream, c, ia, h->cbest,
                          h->chunk_iters);
-    else if (c.algo == RRTX_ALGO_DUBINS)
+    else if (is_dubins(c.algo))
       hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(B), dim3(rppd::TPB), 0, h->stream, c, h->da, h->chunk_iters);
     else
       hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);
@@ -591,7 +594,7 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
     HIPCHK(h, hipMemcpy(xy, d, sizeof(double) * 2 * oi[3], hipMemcpyDeviceToHost));
     return RRTX_OK;
   }
-  if (h->p.algo == RRTX_ALGO_DUBINS) {
+  if (is_dubins(h->p.algo)) {
     // generate_final_course (rrt_05:1512-1521): [goal] + reversed edge polylines up the parent chain + [start]
     const int n = I.n;
     const int64_t off = (int64_t)instance * h->stride;
@@ -679,7 +682,7 @@ int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes) {
 
 int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap) {
   if (!h || !yaw || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
-  if (!h->planned || h->p.algo != RRTX_ALGO_DUBINS) return RRTX_E_STATE;
+  if (!h->planned || !is_dubins(h->p.algo)) return RRTX_E_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   Result r;
   HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));
@@ -691,7 +694,7 @@ int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap) {
 int rrtx_get_polylines(rrtx_handle* h, int32_t instance, int32_t* plen, int32_t cap_nodes, double* px, double* py,
                        int64_t cap_points, int64_t* n_points_out) {
   if (!h || !n_points_out || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
-  if (!h->planned || h->p.algo != RRTX_ALGO_DUBINS) return RRTX_E_STATE;
+  if (!h->planned || !is_dubins(h->p.algo)) return RRTX_E_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   Result r;
   HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));

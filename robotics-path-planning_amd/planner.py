@@ -390,13 +390,8 @@ class RRTStarDubins:
 
     def planning(self, animation=True, search_until_max_iter=True):
         if not search_until_max_iter:
-            raise NotImplementedError("rrt_05's early-exit mode is not built yet (the driver never uses it)")
-        h = _abi.Handle(_abi.ALGO_DUBINS, [self.start.x, self.start.y, self.start.yaw],
-                        [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], self.expand_dis,
-                        self.path_resolution, self.goal_sample_rate, self.max_iter, robot_radius=self.robot_radius,
-                        connect_circle_dist=self.connect_circle_dist, search_until_max_iter=True, n_instances=1,
-                        device=self.device, curvature=self.curvature, goal_yaw_th=self.goal_yaw_th,
-                        goal_xy_th=self.goal_xy_th)
+            raise NotImplementedError("the early-exit mode is not built yet (the reference's drivers never use it)")
+        h = self._make_handle()
         try:
             h.set_obstacles(self.obstacle_list)
             st = random.getstate()
@@ -424,6 +419,7 @@ class RRTStarDubins:
             self.polylines = (plen, px, py)
             path = h.get_path(0)
             self.stats = h.get_stats()
+            self._after_plan(h)
             if self._trace:
                 self.trace = h.get_trace()
         finally:
@@ -431,6 +427,47 @@ class RRTStarDubins:
         return None if path is None else [[float(a), float(b)] for a, b in path]
 
     plan = planning
+
+    def _make_handle(self):
+        return _abi.Handle(_abi.ALGO_DUBINS, [self.start.x, self.start.y, self.start.yaw],
+                           [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], self.expand_dis,
+                           self.path_resolution, self.goal_sample_rate, self.max_iter, robot_radius=self.robot_radius,
+                           connect_circle_dist=self.connect_circle_dist, search_until_max_iter=True, n_instances=1,
+                           device=self.device, curvature=self.curvature, goal_yaw_th=self.goal_yaw_th,
+                           goal_xy_th=self.goal_xy_th)
+
+    def _after_plan(self, h):
+        pass
+
+
+class RRTDubins(RRTStarDubins):
+    """Drop-in for rrt_03's `RRT` (10_path_planning_01_rrt_03_dubins_path.py:1348-1700): RRT whose steer is the whole
+    Dubins path to the sample, node cost = Dubins length (:1458-1481).  `sobol_sampler=True` (the driver's setting)
+    draws the 3-D Sobol point of :1545-1563.  As shipped that script stops at import (its word table :1030 names
+    functions defined later); the behaviour mirrored here is the one its classes define, pinned by goldens generated
+    with that one assignment evaluated after the definitions (oracle/ref_loader.py)."""
+
+    def __init__(self, start, goal, obstacle_list, rand_area, goal_sample_rate=10, max_iter=200, play_area=None,
+                 robot_radius=0.0, sobol_sampler=False, curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)),
+                 goal_xy_th=0.5, device=0):
+        super().__init__(start, goal, obstacle_list, rand_area, goal_sample_rate=goal_sample_rate, max_iter=max_iter,
+                         play_area=play_area, robot_radius=robot_radius, sobol_sampler=sobol_sampler,
+                         curvature=curvature, goal_yaw_th=goal_yaw_th, goal_xy_th=goal_xy_th, device=device)
+
+    def _make_handle(self):
+        return _abi.Handle(_abi.ALGO_RRT_DUBINS, [self.start.x, self.start.y, self.start.yaw],
+                           [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], 0.0, 0.5,
+                           self.goal_sample_rate, self.max_iter,
+                           play_area=None if self.play_area is None else [self.play_area.xmin, self.play_area.xmax,
+                                                                          self.play_area.ymin, self.play_area.ymax],
+                           robot_radius=self.robot_radius,
+                           sampler=_abi.SAMPLER_SOBOL if self.sobol_sampler else _abi.SAMPLER_MT,
+                           search_until_max_iter=True, n_instances=1, device=self.device, curvature=self.curvature,
+                           goal_yaw_th=self.goal_yaw_th, goal_xy_th=self.goal_xy_th)
+
+    def _after_plan(self, h):
+        if self.sobol_sampler:
+            self.sobol_inter_ = h.get_sobol_index(0)
 
 
 def bitstar_rotation(start_xy, goal_xy):

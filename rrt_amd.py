@@ -13,6 +13,7 @@ RRT = _pkg.RRT
 RRTStar = _pkg.RRTStar
 RRTSobol = _pkg.RRTSobol
 RRTStarDubins = _pkg.RRTStarDubins
+RRTDubins = _pkg.RRTDubins
 BITStar = _pkg.BITStar
 bitstar_rotation = _pkg.bitstar_rotation
 InformedRRTStar = _pkg.InformedRRTStar

@@ -317,6 +317,70 @@ def _bit_coords(ids, rand_min=-2.0):
     return rand_min + 0.01 * c0, rand_min + 0.01 * c1
 
 
+@pytest.mark.parametrize("path", util.golden_files("rrt03"), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_rrt_dubins_matches_reference_golden(gpu, path):
+    """rrt_03 (RRT with Dubins steer, MT and 3-D Sobol samplers): poses, Dubins-length costs, parents, stored edge
+    polylines, final course, RNG state and Sobol index equal the reference's, bit for bit."""
+    g = util.load_golden(path)
+    out = util.run_gpu_rrt_dubins(g, [int(g["seed"])], trace_instance=0)
+    x, y, cost, parent = out["trees"][0]
+    tr = out["trace"]
+    n = len(g["tr_nearest"])
+    assert np.array_equal(tr[0][:n], g["tr_rx"]) and np.array_equal(tr[2][:n], g["tr_nearest"])
+    util.assert_tree_equal((x, y, cost, parent), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(out["yaws"][0], g["yaw"])
+    plen, px, py = out["polys"][0]
+    assert np.array_equal(plen, g["poly_len"]) and np.array_equal(px, g["poly_x"]) and np.array_equal(py, g["poly_y"])
+    p = out["paths"][0]
+    if len(g["path"]) == 0:
+        assert p is None
+    else:
+        assert p is not None and np.array_equal(p, g["path"])
+    st = out["rng"][0]
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+    if int(g["sobol"]):
+        assert out["sobol"][0] == int(g["sobol_index_after"])
+
+
+def test_gpu_rrt_dubins_batch_equals_oracle(gpu):
+    """rrt_03 batch: instance i == oracle(seed i) at 2 000 iterations (beyond the goldens), both samplers."""
+    import oracle
+    g = util.load_golden(util.GOLDEN + "/rrt03_drv_s42_it200_sobol.npz")
+    for sob in (1, 0):
+        g2 = dict(g)
+        g2["max_iter"] = 2000
+        g2["sobol"] = sob
+        seeds = list(range(1, 17))
+        out = util.run_gpu_rrt_dubins(g2, seeds)
+        for i, sd in enumerate(seeds):
+            r = oracle.plan_rrt_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], 2000, seed=sd,
+                                       robot_radius=float(g["robot_radius"]), goal_sample_rate=int(g["goal_sample_rate"]),
+                                       sobol=bool(sob))
+            util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % sd)
+            assert np.array_equal(out["yaws"][i], r["yaw"])
+            p = out["paths"][i]
+            assert (p is None and r["path"] is None) or np.array_equal(p, r["path"])
+
+
+def test_rrt_dubins_host_class_drop_in(gpu):
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt03_drv_s42_it200_sobol.npz")
+    random.seed(int(g["seed"]))
+    rrt = rrt_amd.RRTDubins(start=[float(v) for v in g["start"]], goal=[float(v) for v in g["goal"]],
+                            obstacle_list=[tuple(float(v) for v in o) for o in g["obstacles"]],
+                            rand_area=[float(v) for v in g["rand_area"]], goal_sample_rate=10, max_iter=200,
+                            play_area=None, robot_radius=0.6, sobol_sampler=True, curvature=1.0,
+                            goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5)
+    path = rrt.planning(animation=False)
+    assert path is not None and np.array_equal(np.array(path), g["path"])
+    assert len(rrt.node_list) == len(g["x"]) and rrt.node_list[-1].cost == float(g["cost"][-1])
+    assert rrt.node_list[5].parent is rrt.node_list[int(g["parent"][5])]
+    assert rrt.sobol_inter_ == int(g["sobol_index_after"])
+    st = random.getstate()
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
 @pytest.mark.parametrize("path", util.golden_files("rrt08"), ids=lambda p: p.split("/")[-1][:-4])
 def test_gpu_bitstar_matches_reference_golden(gpu, path):
     """rrt_08 BIT* on the GPU vs the reference goldens: popped-edge sequence, tree vertices (grid coordinates),

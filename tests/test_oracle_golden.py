@@ -112,6 +112,31 @@ def test_dubins_rrt_star_oracle_matches_reference_golden(path):
     assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])
 
 
+@pytest.mark.parametrize("path", util.golden_files("rrt03"), ids=lambda p: p.split("/")[-1][:-4])
+def test_rrt_dubins_oracle_matches_reference_golden(path):
+    """rrt_03 RRT with Dubins steer (pseudo-random and 3-D Sobol sampler): poses, Dubins-length costs, parents, every
+    stored edge polyline, final course, RNG state and Sobol index."""
+    import oracle
+    g = util.load_golden(path)
+    r = oracle.plan_rrt_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]),
+                               seed=int(g["seed"]), robot_radius=float(g["robot_radius"]),
+                               goal_sample_rate=int(g["goal_sample_rate"]), sobol=bool(int(g["sobol"])), trace=True)
+    util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(r["yaw"], g["yaw"])
+    assert np.array_equal(r["poly_len"], g["poly_len"]) and np.array_equal(r["poly_x"], g["poly_x"]) \
+        and np.array_equal(r["poly_y"], g["poly_y"])
+    if len(g["path"]) == 0:
+        assert r["path"] is None
+    else:
+        assert r["path"] is not None and np.array_equal(r["path"], g["path"])
+    assert r["rng"].pos == int(g["rng_pos_after"]) and r["rng"].mt[0] == int(g["rng_word0_after"])
+    if int(g["sobol"]):
+        assert r["sobol_index"] == int(g["sobol_index_after"])
+    n = len(g["tr_nearest"])
+    assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])
+    assert np.array_equal(r["tr_rx"][:n], g["tr_rx"])
+
+
 @pytest.mark.parametrize("path", util.golden_files("rrt08"), ids=lambda p: p.split("/")[-1][:-4])
 def test_bitstar_oracle_matches_reference_golden(path):
     """rrt_08 BIT*: vertex insertion order, g-scores, parents, returned path, tree edge / sample counts, the whole

@@ -181,6 +181,36 @@ def run_gpu_dubins(g, seeds, device=0, trace_instance=None, max_iter=None):
     return out
 
 
+def run_gpu_rrt_dubins(g, seeds, device=0, trace_instance=None):
+    """RRT with Dubins steer (rrt_03) instances on the GPU through the C ABI; g = golden dict (parameters)."""
+    import rrt_amd
+    A = rrt_amd._abi
+    h = A.Handle(A.ALGO_RRT_DUBINS, [float(v) for v in g["start"]], [float(v) for v in g["goal"]],
+                 [float(v) for v in g["rand_area"]], 0.0, 0.5, int(g["goal_sample_rate"]), int(g["max_iter"]),
+                 robot_radius=float(g["robot_radius"]), sampler=A.SAMPLER_SOBOL if int(g["sobol"]) else A.SAMPLER_MT,
+                 search_until_max_iter=True, n_instances=len(seeds), device=device, curvature=float(g["curvature"]),
+                 goal_yaw_th=float(g["goal_yaw_th"]), goal_xy_th=float(g["goal_xy_th"]))
+    try:
+        h.set_obstacles([tuple(float(v) for v in o) for o in g["obstacles"]])
+        h.seed_instances(seeds)
+        if trace_instance is not None:
+            h.enable_trace(trace_instance)
+        h.plan()
+        out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], yaws=[], polys=[], paths=[], rng=[], sobol=[])
+        for i in range(len(seeds)):
+            out["trees"].append(h.get_tree(i))
+            out["yaws"].append(h.get_yaw(i))
+            out["polys"].append(h.get_polylines(i))
+            out["paths"].append(h.get_path(i))
+            out["rng"].append(h.get_rng_state(i))
+            out["sobol"].append(h.get_sobol_index(i))
+        if trace_instance is not None:
+            out["trace"] = h.get_trace()
+    finally:
+        h.close()
+    return out
+
+
 def run_gpu_bitstar(obstacles, rand_area, max_iter, seeds, starts, goals, device=0, trace_instance=None):
     """BIT* (rrt_08) instances on the GPU through the C ABI; per-instance start / goal / rotation."""
     import rrt_amd
