@@ -285,7 +285,7 @@ def main02():
 
 # ------------------------------------------------------------------------------------------------ rrt_05
 def run_rrt05(mod, name, obstacles, start, goal, rand_area, max_iter, seed, curvature=1.0, robot_radius=0.0,
-              goal_sample_rate=10, expand_dis=3.0, ccd=50.0):
+              goal_sample_rate=10, expand_dis=3.0, ccd=50.0, until_max=True):
     """RRT*-Dubins (rrt_05:1335-1795), driver-style call planning(animation=False)."""
     random.seed(seed)
     rrt = mod.RRT(start=start, goal=goal, obstacle_list=obstacles, rand_area=rand_area, expand_dis=expand_dis,
@@ -310,7 +310,7 @@ def run_rrt05(mod, name, obstacles, start, goal, rand_area, max_iter, seed, curv
     rrt.find_near_nodes = fn_hook
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
-        path = rrt.planning(animation=False)
+        path = rrt.planning(animation=False) if until_max else rrt.planning(animation=False, search_until_max_iter=False)
     dt = time.time() - t0
     nl = rrt.node_list
     x, y, cost, parent = tree_arrays(nl)
@@ -319,7 +319,7 @@ def run_rrt05(mod, name, obstacles, start, goal, rand_area, max_iter, seed, curv
     ppx = np.concatenate([np.asarray(nd.path_x, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
     ppy = np.concatenate([np.asarray(nd.path_y, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
     state = random.getstate()
-    out = dict(algo="rrt_star_dubins", seed=seed, obstacles=np.array(obstacles, dtype=np.float64),
+    out = dict(algo="rrt_star_dubins", seed=seed, search_until_max_iter=int(bool(until_max)), obstacles=np.array(obstacles, dtype=np.float64),
                start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
                rand_area=np.array(rand_area, dtype=np.float64), max_iter=max_iter, curvature=curvature,
                robot_radius=robot_radius, goal_sample_rate=goal_sample_rate, expand_dis=expand_dis,
@@ -367,7 +367,7 @@ def main05(only=""):
 
 # ------------------------------------------------------------------------------------------------ rrt_03
 def run_rrt03(mod, name, obstacles, start, goal, rand_area, max_iter, seed, sobol, curvature=1.0, robot_radius=0.6,
-              goal_sample_rate=10):
+              goal_sample_rate=10, until_max=True):
     """RRT with Dubins steer (rrt_03:1348-1700), driver-style call planning(animation=False)."""
     ref_loader.reset_sobol(mod)
     random.seed(seed)
@@ -385,7 +385,7 @@ def run_rrt03(mod, name, obstacles, start, goal, rand_area, max_iter, seed, sobo
     rrt.get_nearest_node_index = near_hook
     t0 = time.time()
     with contextlib.redirect_stdout(io.StringIO()):
-        path = rrt.planning(animation=False)
+        path = rrt.planning(animation=False) if until_max else rrt.planning(animation=False, search_until_max_iter=False)
     dt = time.time() - t0
     nl = rrt.node_list
     x, y, cost, parent = tree_arrays(nl)
@@ -394,7 +394,7 @@ def run_rrt03(mod, name, obstacles, start, goal, rand_area, max_iter, seed, sobo
     ppx = np.concatenate([np.asarray(nd.path_x, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
     ppy = np.concatenate([np.asarray(nd.path_y, dtype=np.float64).reshape(-1) for nd in nl]) if len(nl) else np.zeros(0)
     state = random.getstate()
-    out = dict(algo="rrt_dubins", seed=seed, sobol=int(bool(sobol)), obstacles=np.array(obstacles, dtype=np.float64),
+    out = dict(algo="rrt_dubins", seed=seed, search_until_max_iter=int(bool(until_max)), sobol=int(bool(sobol)), obstacles=np.array(obstacles, dtype=np.float64),
                start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
                rand_area=np.array(rand_area, dtype=np.float64), max_iter=max_iter, curvature=curvature,
                robot_radius=robot_radius, goal_sample_rate=goal_sample_rate, goal_yaw_th=float(np.deg2rad(1.0)),
@@ -419,6 +419,23 @@ def main03(only=""):
         n = "rrt03_drv_s%d_it%d_%s" % (seed, it, "sobol" if sob else "mt")
         if n.startswith(only):
             run_rrt03(m03, n, max_iter=it, seed=seed, sobol=sob, **drv)
+
+
+def main_early(only=""):
+    """planning(animation=False, search_until_max_iter=False): the early-return mode of rrt_03 / rrt_05 (:1443-1446)."""
+    obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)]
+    drv = dict(obstacles=obst, start=[0.0, 0.0, float(np.deg2rad(0.0))], goal=[10.0, 10.0, float(np.deg2rad(0.0))],
+               rand_area=[-2, 15])
+    m03 = ref_loader.load("rrt_03")
+    for seed, it, sob in ((42, 1500, 1), (1, 1500, 0), (5, 1500, 0), (8, 60, 1)):
+        n = "rrt03_early_s%d_it%d_%s" % (seed, it, "sobol" if sob else "mt")
+        if n.startswith(only):
+            run_rrt03(m03, n, max_iter=it, seed=seed, sobol=sob, until_max=False, **drv)
+    m05 = ref_loader.load("rrt_05")
+    for seed, it in ((42, 2000), (3, 1500), (9, 1500), (4, 100)):
+        n = "rrt05_early_s%d_it%d" % (seed, it)
+        if n.startswith(only):
+            run_rrt05(m05, n, max_iter=it, seed=seed, until_max=False, **drv)
 
 
 def math_pi():

@@ -206,16 +206,17 @@ def dubins(sx, sy, syaw, gx, gy, gyaw, curvature=1.0, cap=4096):
 
 def plan_rrt_dubins(start, goal, obstacles, rand_area, max_iter=200, seed=None, rng=None, curvature=1.0,
                     robot_radius=0.0, goal_sample_rate=10, goal_yaw_th=None, goal_xy_th=0.5, sobol=False, play_area=None,
-                    trace=False):
+                    trace=False, search_until_max_iter=True):
     """One RRT.planning(animation=False) call of rrt_03 (RRT with Dubins steer) on the oracle."""
     return plan_dubins(start, goal, obstacles, rand_area, max_iter, seed=seed, rng=rng, curvature=curvature,
                        robot_radius=robot_radius, goal_sample_rate=goal_sample_rate, goal_yaw_th=goal_yaw_th,
-                       goal_xy_th=goal_xy_th, trace=trace, _plain=True, _sobol=sobol, _play_area=play_area)
+                       goal_xy_th=goal_xy_th, trace=trace, search_until_max_iter=search_until_max_iter, _plain=True,
+                       _sobol=sobol, _play_area=play_area)
 
 
 def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=None, curvature=1.0, robot_radius=0.0,
                 goal_sample_rate=10, expand_dis=3.0, connect_circle_dist=50.0, goal_yaw_th=None, goal_xy_th=0.5,
-                trace=False, _plain=False, _sobol=False, _play_area=None):
+                trace=False, search_until_max_iter=True, _plain=False, _sobol=False, _play_area=None):
     """One RRT.planning(animation=False) call of rrt_05 (RRT*-Dubins) on the oracle."""
     L = lib()
     L.orc_plan_dubins.restype = C.c_int
@@ -226,6 +227,7 @@ def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=
     p = Params()
     p.algo = 3
     p.sobol = int(bool(_sobol))
+    p.search_until_max_iter = int(bool(search_until_max_iter))
     if _play_area is not None:
         p.has_play_area = 1
         for k in range(4):

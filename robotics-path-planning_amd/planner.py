@@ -389,9 +389,7 @@ class RRTStarDubins:
         self.trace = None
 
     def planning(self, animation=True, search_until_max_iter=True):
-        if not search_until_max_iter:
-            raise NotImplementedError("the early-exit mode is not built yet (the reference's drivers never use it)")
-        h = self._make_handle()
+        h = self._make_handle(bool(search_until_max_iter))
         try:
             h.set_obstacles(self.obstacle_list)
             st = random.getstate()
@@ -428,11 +426,11 @@ class RRTStarDubins:
 
     plan = planning
 
-    def _make_handle(self):
+    def _make_handle(self, until_max=True):
         return _abi.Handle(_abi.ALGO_DUBINS, [self.start.x, self.start.y, self.start.yaw],
                            [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], self.expand_dis,
                            self.path_resolution, self.goal_sample_rate, self.max_iter, robot_radius=self.robot_radius,
-                           connect_circle_dist=self.connect_circle_dist, search_until_max_iter=True, n_instances=1,
+                           connect_circle_dist=self.connect_circle_dist, search_until_max_iter=until_max, n_instances=1,
                            device=self.device, curvature=self.curvature, goal_yaw_th=self.goal_yaw_th,
                            goal_xy_th=self.goal_xy_th)
 
@@ -454,7 +452,7 @@ class RRTDubins(RRTStarDubins):
                          play_area=play_area, robot_radius=robot_radius, sobol_sampler=sobol_sampler,
                          curvature=curvature, goal_yaw_th=goal_yaw_th, goal_xy_th=goal_xy_th, device=device)
 
-    def _make_handle(self):
+    def _make_handle(self, until_max=True):
         return _abi.Handle(_abi.ALGO_RRT_DUBINS, [self.start.x, self.start.y, self.start.yaw],
                            [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], 0.0, 0.5,
                            self.goal_sample_rate, self.max_iter,
@@ -462,7 +460,7 @@ class RRTDubins(RRTStarDubins):
                                                                           self.play_area.ymin, self.play_area.ymax],
                            robot_radius=self.robot_radius,
                            sampler=_abi.SAMPLER_SOBOL if self.sobol_sampler else _abi.SAMPLER_MT,
-                           search_until_max_iter=True, n_instances=1, device=self.device, curvature=self.curvature,
+                           search_until_max_iter=until_max, n_instances=1, device=self.device, curvature=self.curvature,
                            goal_yaw_th=self.goal_yaw_th, goal_xy_th=self.goal_xy_th)
 
     def _after_plan(self, h):

@@ -362,6 +362,33 @@ def test_gpu_rrt_dubins_batch_equals_oracle(gpu):
             assert (p is None and r["path"] is None) or np.array_equal(p, r["path"])
 
 
+def test_dubins_host_classes_early_return(gpu):
+    """planning(animation=False, search_until_max_iter=False) of rrt_05 and rrt_03 (:1443-1446): returns at the first
+    iteration whose tree holds a goal node; tree, path and RNG state as the reference leaves them."""
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt05_early_s3_it1500.npz")
+    obst = [tuple(float(v) for v in o) for o in g["obstacles"]]
+    random.seed(int(g["seed"]))
+    rrt = rrt_amd.RRTStarDubins(start=[float(v) for v in g["start"]], goal=[float(v) for v in g["goal"]],
+                                obstacle_list=obst, rand_area=[float(v) for v in g["rand_area"]], expand_dis=3.0,
+                                path_resolution=0.5, goal_sample_rate=10, max_iter=int(g["max_iter"]), robot_radius=0.0,
+                                connect_circle_dist=50.0, curvature=1.0)
+    path = rrt.planning(animation=False, search_until_max_iter=False)
+    assert np.array_equal(np.array(path), g["path"]) and len(rrt.node_list) == len(g["x"])
+    st = random.getstate()
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+    g = util.load_golden(util.GOLDEN + "/rrt03_early_s1_it1500_mt.npz")
+    random.seed(int(g["seed"]))
+    rrt = rrt_amd.RRTDubins(start=[float(v) for v in g["start"]], goal=[float(v) for v in g["goal"]], obstacle_list=obst,
+                            rand_area=[float(v) for v in g["rand_area"]], goal_sample_rate=10,
+                            max_iter=int(g["max_iter"]), robot_radius=0.6, sobol_sampler=False, curvature=1.0)
+    path = rrt.planning(animation=False, search_until_max_iter=False)
+    assert np.array_equal(np.array(path), g["path"]) and len(rrt.node_list) == len(g["x"])
+    st = random.getstate()
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
 def test_rrt_dubins_host_class_drop_in(gpu):
     import random
     import rrt_amd

@@ -98,7 +98,7 @@ def test_dubins_rrt_star_oracle_matches_reference_golden(path):
     import oracle
     g = util.load_golden(path)
     r = oracle.plan_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]), seed=int(g["seed"]),
-                           trace=True)
+                           trace=True, search_until_max_iter=bool(int(g.get("search_until_max_iter", 1))))
     util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
     assert np.array_equal(r["yaw"], g["yaw"])
     assert np.array_equal(r["poly_len"], g["poly_len"]) and np.array_equal(r["poly_x"], g["poly_x"]) \
@@ -120,7 +120,8 @@ def test_rrt_dubins_oracle_matches_reference_golden(path):
     g = util.load_golden(path)
     r = oracle.plan_rrt_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]),
                                seed=int(g["seed"]), robot_radius=float(g["robot_radius"]),
-                               goal_sample_rate=int(g["goal_sample_rate"]), sobol=bool(int(g["sobol"])), trace=True)
+                               goal_sample_rate=int(g["goal_sample_rate"]), sobol=bool(int(g["sobol"])), trace=True,
+                               search_until_max_iter=bool(int(g.get("search_until_max_iter", 1))))
     util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
     assert np.array_equal(r["yaw"], g["yaw"])
     assert np.array_equal(r["poly_len"], g["poly_len"]) and np.array_equal(r["poly_x"], g["poly_x"]) \

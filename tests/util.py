@@ -159,7 +159,8 @@ def run_gpu_dubins(g, seeds, device=0, trace_instance=None, max_iter=None):
     h = A.Handle(A.ALGO_DUBINS, [float(v) for v in g["start"]], [float(v) for v in g["goal"]],
                  [float(v) for v in g["rand_area"]], float(g["expand_dis"]), 0.5, int(g["goal_sample_rate"]), mi,
                  robot_radius=float(g["robot_radius"]), connect_circle_dist=float(g["connect_circle_dist"]),
-                 search_until_max_iter=True, n_instances=len(seeds), device=device, curvature=float(g["curvature"]),
+                 search_until_max_iter=bool(int(g.get("search_until_max_iter", 1))), n_instances=len(seeds),
+                 device=device, curvature=float(g["curvature"]),
                  goal_yaw_th=float(g["goal_yaw_th"]), goal_xy_th=float(g["goal_xy_th"]))
     try:
         h.set_obstacles([tuple(float(v) for v in o) for o in g["obstacles"]])
@@ -188,7 +189,8 @@ def run_gpu_rrt_dubins(g, seeds, device=0, trace_instance=None):
     h = A.Handle(A.ALGO_RRT_DUBINS, [float(v) for v in g["start"]], [float(v) for v in g["goal"]],
                  [float(v) for v in g["rand_area"]], 0.0, 0.5, int(g["goal_sample_rate"]), int(g["max_iter"]),
                  robot_radius=float(g["robot_radius"]), sampler=A.SAMPLER_SOBOL if int(g["sobol"]) else A.SAMPLER_MT,
-                 search_until_max_iter=True, n_instances=len(seeds), device=device, curvature=float(g["curvature"]),
+                 search_until_max_iter=bool(int(g.get("search_until_max_iter", 1))), n_instances=len(seeds),
+                 device=device, curvature=float(g["curvature"]),
                  goal_yaw_th=float(g["goal_yaw_th"]), goal_xy_th=float(g["goal_xy_th"]))
     try:
         h.set_obstacles([tuple(float(v) for v in o) for o in g["obstacles"]])
