@@ -160,6 +160,23 @@ int rrtx_device_count(void);
 /* Evaluate the device scalar core on arrays (parity harness for the glibc/CPython arithmetic replicas):
  * op 0: math.hypot(a,b)  1: a**2  2: math.sin(a)  3: math.cos(a)  4: math.atan2(a,b)
  * op 5: steer end x of (0,0)->(a,b) with extend=inf, res=0.25   6: sqrt(a)  7: a/b */
+/* Path smoothing: replaces path_smoothing(path, max_iter, obstacle_list) (rrt_04:1447-1479; get_path_length :1391,
+ * get_target_point :1401, line_collision_check :1423 -- the infinite-line distance test is kept), which every driver
+ * runs right after planning() on the path it returned, drawing from the same MT19937 stream (rrt_04:1558-1559).
+ *
+ * rrtx_smooth_paths: a batch of polylines from the host.  Job j: path_n[j] points at paths_xy + 2*j*in_stride
+ * (goal -> start order as planning() returns them), RNG state mt_words[624*j .. ], mt_pos[j] (advanced in place, so
+ * random.getstate() afterwards equals the reference's); result out_n[j] points at out_xy + 2*j*out_stride;
+ * status[j] = 0 ok, 1 capacity (more than 512 points / 256 obstacles), 2 the reference raises ZeroDivisionError.
+ * obst_xyr = m rows (ox, oy, size) -- sizes as given, no robot radius (:1441). */
+int rrtx_smooth_paths(int32_t device, int32_t n_jobs, const double* paths_xy, const int32_t* path_n, int32_t in_stride,
+                      int32_t max_iter, const double* obst_xyr, int32_t m, uint32_t* mt_words, int32_t* mt_pos,
+                      double* out_xy, int32_t out_stride, int32_t* out_n, int32_t* status);
+/* The same on the paths a handle just planned (RRTX_ALGO_RRT / RRTX_ALGO_RRT_STAR), entirely on the device: every
+ * instance's path is smoothed continuing that instance's RNG stream (rrtx_get_rng_state afterwards = after smoothing). */
+int rrtx_smooth_planned(rrtx_handle* h, int32_t max_iter);
+int rrtx_get_smoothed_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_points, int32_t* n_out);
+
 int rrtx_selftest_math(int32_t device, int32_t op, const double* a, const double* b, double* out, int64_t n);
 
 #ifdef __cplusplus

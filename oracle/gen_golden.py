@@ -438,6 +438,72 @@ def main_early(only=""):
             run_rrt05(m05, n, max_iter=it, seed=seed, until_max=False, **drv)
 
 
+def main_smooth(only=""):
+    """path_smoothing (rrt_04:1447-1479) as the driver uses it (:1548-1559): random.seed -> planning() ->
+    path_smoothing(path, 1000, obstacleList) on the stream planning() left behind; plus stand-alone polylines."""
+    m04 = ref_loader.load("rrt_04")
+
+    def smooth_and_store(name, path, iters, obst):
+        st0 = random.getstate()
+        t0 = time.time()
+        sm = m04.path_smoothing([list(p) for p in path], iters, obst)
+        dt = time.time() - t0
+        st1 = random.getstate()
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), algo="path_smoothing",
+                            path_in=np.array(path, dtype=np.float64), smoothed=np.array(sm, dtype=np.float64),
+                            max_iter=iters, obstacles=np.array(obst, dtype=np.float64),
+                            rng_mt_before=np.array(st0[1][:624], dtype=np.uint32), rng_pos_before=st0[1][624],
+                            rng_pos_after=st1[1][624], rng_word0_after=np.uint32(st1[1][0]),
+                            len_in=float(m04.get_path_length(path)), len_out=float(m04.get_path_length(sm)))
+        print("%-28s in=%d out=%d len %.4f -> %.4f  %.2fs" % (name, len(path), len(sm), m04.get_path_length(path),
+                                                               m04.get_path_length(sm), dt), flush=True)
+
+    drv = dict(obstacles=DRIVER_OBST, start=[0, 0], goal=[6.0, 10.0], rand_area=[-2, 15], expand_dis=1.0,
+               path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=[0, 10, 0, 14], robot_radius=0.6)
+    for seed in (1234, 5, 42, 7):
+        name = "smooth_drv_s%d" % seed
+        if not name.startswith(only):
+            continue
+        ref_loader.reset_sobol(m04)
+        random.seed(seed)
+        rrt = m04.RRT(start=drv["start"], goal=drv["goal"], obstacle_list=drv["obstacles"], rand_area=drv["rand_area"],
+                      expand_dis=drv["expand_dis"], path_resolution=drv["path_resolution"],
+                      goal_sample_rate=drv["goal_sample_rate"], max_iter=drv["max_iter"], play_area=drv["play_area"],
+                      robot_radius=drv["robot_radius"], sobol_sampler=False, connect_circle_dist=50.0,
+                      search_until_max_iter=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            path = rrt.planning(animation=False)
+        if path is not None:
+            smooth_and_store(name, path, 1000, drv["obstacles"])
+    # C2-style map, longer path
+    c2 = dict(obstacles=synth_map(7, 50), start=[2.0, 2.0], goal=[98.0, 98.0], rand_area=[0, 100])
+    for seed in (1, 3):
+        name = "smooth_c2_s%d" % seed
+        if not name.startswith(only):
+            continue
+        ref_loader.reset_sobol(m04)
+        random.seed(seed)
+        rrt = m04.RRT(start=c2["start"], goal=c2["goal"], obstacle_list=c2["obstacles"], rand_area=c2["rand_area"],
+                      expand_dis=2.0, path_resolution=0.25, goal_sample_rate=5, max_iter=2500, play_area=None,
+                      robot_radius=0.0, sobol_sampler=False, connect_circle_dist=50.0, search_until_max_iter=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            path = rrt.planning(animation=False)
+        if path is not None:
+            smooth_and_store(name, path, 1000, c2["obstacles"])
+    # stand-alone polylines (no planner): a staircase through free space, own seed
+    for seed, npts in ((11, 40), (12, 150)):
+        name = "smooth_poly_s%d" % seed
+        if not name.startswith(only):
+            continue
+        rng = random.Random(100 + seed)
+        pts = [[0.0, 0.0]]
+        for k in range(npts):
+            pts.append([pts[-1][0] + rng.uniform(0.2, 1.0), pts[-1][1] + rng.uniform(-0.8, 1.0)])
+        obst = [(pts[npts // 3][0] + 3.0, pts[npts // 3][1] - 3.0, 1.0), (pts[2 * npts // 3][0] - 3.0, pts[2 * npts // 3][1] + 4.0, 1.5)]
+        random.seed(seed)
+        smooth_and_store(name, pts[::-1], 600, obst)
+
+
 def math_pi():
     import math
     return math.pi

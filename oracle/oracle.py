@@ -331,3 +331,21 @@ def plan_bitstar(start, goal, obstacles, rand_area, max_iter=80, seed=None, rng=
     return dict(path=path[:o.path_n].copy(), vertex_ids=vid[:o.nv].copy(), g_scores=g[:o.nv].copy(),
                 parent_ids=par[:o.nv].copy(), n_edges=o.n_edges, n_samples=o.n_samples, error=o.error,
                 tr_e0=t0[:min(o.tr_n, tcap)].copy(), tr_e1=t1[:min(o.tr_n, tcap)].copy(), rng=rng)
+
+
+def path_smoothing(path, max_iter, obstacles, rng):
+    """path_smoothing(path, max_iter, obstacle_list) of rrt_04:1447-1479 on the oracle; `rng` (MT state) advances."""
+    L = lib()
+    L.orc_path_smoothing.restype = C.c_int
+    L.orc_path_smoothing.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                     C.c_void_p]
+    pin = np.ascontiguousarray(np.array(path, dtype=np.float64).reshape(-1, 2))
+    obst = np.ascontiguousarray(np.array(obstacles, dtype=np.float64).reshape(-1, 3))
+    cap = len(pin) + int(max_iter) + 8
+    out = np.zeros((cap, 2))
+    n = C.c_int(0)
+    rc = L.orc_path_smoothing(pin.ctypes.data, len(pin), int(max_iter), obst.ctypes.data, len(obst), C.byref(rng),
+                              out.ctypes.data, cap, C.byref(n))
+    if rc != 0:
+        raise RuntimeError("orc_path_smoothing failed: %d" % rc)
+    return out[:n.value].copy()

@@ -22,7 +22,8 @@ ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP
 EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
-           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math"]
+           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
+           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path"]
 
 
 class Params(C.Structure):
@@ -91,6 +92,9 @@ def load():
     L.rrtx_destroy.argtypes = [vp]
     L.rrtx_destroy.restype = None
     L.rrtx_selftest_math.argtypes = [i32, i32, vp, vp, vp, C.c_int64]
+    L.rrtx_smooth_paths.argtypes = [i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp]
+    L.rrtx_smooth_planned.argtypes = [vp, i32]
+    L.rrtx_get_smoothed_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     for f in EXPORTS:
         if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
             getattr(L, f).restype = C.c_int
@@ -248,6 +252,19 @@ class Handle:
         self._chk(self.L.rrtx_get_sobol_index(self._h, instance, C.byref(v)), "rrtx_get_sobol_index")
         return v.value
 
+    def smooth_planned(self, max_iter):
+        self._chk(self.L.rrtx_smooth_planned(self._h, int(max_iter)), "rrtx_smooth_planned")
+
+    def get_smoothed_path(self, instance):
+        n = C.c_int32()
+        self._chk(self.L.rrtx_get_smoothed_path(self._h, instance, None, 0, C.byref(n)), "rrtx_get_smoothed_path")
+        if n.value == 0:
+            return None
+        xy = np.zeros((n.value, 2))
+        self._chk(self.L.rrtx_get_smoothed_path(self._h, instance, xy.ctypes.data, n.value, C.byref(n)),
+                  "rrtx_get_smoothed_path")
+        return xy
+
     def get_stats(self):
         s = Stats()
         self._chk(self.L.rrtx_get_stats(self._h, C.byref(s)), "rrtx_get_stats")
@@ -266,6 +283,34 @@ class Handle:
                                         C.byref(n)), "rrtx_get_trace")
         k = n.value
         return rx[:k], ry[:k], ne[:k], nn[:k]
+
+
+def smooth_paths(paths, max_iter, obstacles, rng_states, device=0):
+    """Batched path_smoothing (rrt_04:1447-1479) on the GPU.  paths: list of (n_i, 2) arrays; rng_states: list of
+    (mt624 uint32 array, pos).  Returns (list of smoothed (k_i, 2) arrays, list of advanced (mt624, pos), status array)."""
+    L = load()
+    nj = len(paths)
+    stride_in = max(2, max(len(p) for p in paths))
+    pin = np.zeros((nj, stride_in, 2))
+    pn = np.zeros(nj, dtype=np.int32)
+    for j, p in enumerate(paths):
+        a = np.asarray(p, dtype=np.float64).reshape(-1, 2)
+        pin[j, :len(a)] = a
+        pn[j] = len(a)
+    obst = np.ascontiguousarray(np.asarray(obstacles, dtype=np.float64).reshape(-1, 3))
+    words = np.ascontiguousarray(np.stack([np.asarray(s[0], dtype=np.uint32)[:624] for s in rng_states]))
+    pos = np.array([int(s[1]) for s in rng_states], dtype=np.int32)
+    stride_out = stride_in + int(max_iter) + 2
+    stride_out = min(stride_out, 512)
+    out = np.zeros((nj, stride_out, 2))
+    on = np.zeros(nj, dtype=np.int32)
+    st = np.zeros(nj, dtype=np.int32)
+    rc = L.rrtx_smooth_paths(int(device), nj, pin.ctypes.data, pn.ctypes.data, stride_in, int(max_iter),
+                             obst.ctypes.data, len(obst), words.ctypes.data, pos.ctypes.data, out.ctypes.data,
+                             stride_out, on.ctypes.data, st.ctypes.data)
+    if rc != 0:
+        raise RrtxError("rrtx_smooth_paths: %s (status %s)" % (ERRORS.get(rc, rc), st.tolist()))
+    return [out[j, :on[j]].copy() for j in range(nj)], [(words[j].copy(), int(pos[j])) for j in range(nj)], st
 
 
 def selftest_math(op, a, b, device=0):

@@ -19,6 +19,7 @@
 #include "rrt_dubins.hip.h"
 #include "rrt_bitstar.hip.h"
 #include "rrt_bitstar_wave.hip.h"
+#include "path_smooth.hip.h"
 
 using rppk::Ctx;
 using rppk::Inst;
@@ -61,6 +62,12 @@ struct rrtx_handle {
   rppd::DubArgs da;         // RRT*-Dubins device arrays
   rppb::BitArgs ba;         // BIT* device arrays
   std::vector<rpp::BitCfg> bcfg;
+  // path smoothing on the planned paths (rrtx_smooth_planned)
+  double* sm_osz = nullptr;   // obstacle sizes as given (no robot radius), device
+  double* sm_xy = nullptr;    // [inst][sm_stride][2]
+  int32_t *sm_n = nullptr, *sm_status = nullptr;
+  int64_t sm_stride = 0;
+  bool smoothed = false;
 };
 
 #define HIPCHK(h, expr)                                                                      \
@@ -274,6 +281,7 @@ int rrtx_set_obstacles(rrtx_handle* h, const double* oxyr, int32_t m) {
   HIPCHK(h, hipMemcpy((void*)h->c.othr, th.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice));
   h->c.m = m;
   h->m = m;
+  h->obst.assign(oxyr, oxyr + 3 * (size_t)m);
   return RRTX_OK;
 }
 
@@ -773,6 +781,129 @@ int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* neares
   if (rnd_y) HIPCHK(h, hipMemcpy(rnd_y, h->c.tr_ry, sizeof(double) * n, hipMemcpyDeviceToHost));
   if (nearest) HIPCHK(h, hipMemcpy(nearest, h->c.tr_near, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   if (n_near) HIPCHK(h, hipMemcpy(n_near, h->c.tr_nn, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return RRTX_OK;
+}
+
+// ---- path smoothing (rrt_04:1447-1479)
+static int smooth_status_rc(const std::vector<int32_t>& st, std::string* err) {
+  for (int32_t v : st) {
+    if (v == rpps::SM_CAPACITY) {
+      if (err) *err = "path smoothing: polyline or obstacle list exceeds the on-device capacity";
+      return RRTX_E_OVERFLOW;
+    }
+    if (v == rpps::SM_ZERODIV) {
+      if (err) *err = "path smoothing: the reference raises ZeroDivisionError on this input (zero-length pair)";
+      return RRTX_E_STATE;
+    }
+  }
+  return RRTX_OK;
+}
+
+int rrtx_smooth_paths(int32_t device, int32_t n_jobs, const double* paths_xy, const int32_t* path_n, int32_t in_stride,
+                      int32_t max_iter, const double* obst_xyr, int32_t m, uint32_t* mt_words, int32_t* mt_pos,
+                      double* out_xy, int32_t out_stride, int32_t* out_n, int32_t* status) {
+  if (n_jobs < 1 || !paths_xy || !path_n || in_stride < 1 || max_iter < 0 || m < 0 || (m && !obst_xyr) || !mt_words ||
+      !mt_pos || !out_xy || out_stride < 1 || !out_n || !status || m > rpps::MOB)
+    return RRTX_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RRTX_E_NO_DEVICE;
+  if (hipSetDevice(device) != hipSuccess) return RRTX_E_HIP;
+  std::vector<rpp::MT> rng(n_jobs);
+  for (int j = 0; j < n_jobs; j++) {
+    memcpy(rng[j].mt, mt_words + (size_t)j * 624, 624 * 4);
+    rng[j].pos = mt_pos[j];
+  }
+  std::vector<double> ox(m + 1), oy(m + 1), osz(m + 1);
+  for (int k = 0; k < m; k++) {
+    ox[k] = obst_xyr[3 * k];
+    oy[k] = obst_xyr[3 * k + 1];
+    osz[k] = obst_xyr[3 * k + 2];
+  }
+  double *d_in = nullptr, *d_out = nullptr, *d_ox = nullptr, *d_oy = nullptr, *d_osz = nullptr;
+  int32_t *d_n = nullptr, *d_on = nullptr, *d_st = nullptr;
+  rpp::MT* d_rng = nullptr;
+  int rc = RRTX_OK;
+  auto A = [&](void** q, size_t bytes) { if (rc == RRTX_OK && hipMalloc(q, bytes ? bytes : 8) != hipSuccess) rc = RRTX_E_HIP; };
+  A((void**)&d_in, sizeof(double) * 2 * (size_t)in_stride * n_jobs);
+  A((void**)&d_out, sizeof(double) * 2 * (size_t)out_stride * n_jobs);
+  A((void**)&d_ox, sizeof(double) * (m + 1));
+  A((void**)&d_oy, sizeof(double) * (m + 1));
+  A((void**)&d_osz, sizeof(double) * (m + 1));
+  A((void**)&d_n, sizeof(int32_t) * n_jobs);
+  A((void**)&d_on, sizeof(int32_t) * n_jobs);
+  A((void**)&d_st, sizeof(int32_t) * n_jobs);
+  A((void**)&d_rng, sizeof(rpp::MT) * n_jobs);
+  std::vector<int32_t> st(n_jobs, 0);
+  if (rc == RRTX_OK) {
+    bool ok = hipMemcpy(d_in, paths_xy, sizeof(double) * 2 * (size_t)in_stride * n_jobs, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_ox, ox.data(), sizeof(double) * (m + 1), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_oy, oy.data(), sizeof(double) * (m + 1), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_osz, osz.data(), sizeof(double) * (m + 1), hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_n, path_n, sizeof(int32_t) * n_jobs, hipMemcpyHostToDevice) == hipSuccess &&
+              hipMemcpy(d_rng, rng.data(), sizeof(rpp::MT) * n_jobs, hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+      rpps::SmoothArgs a{d_in, in_stride, d_n, 1, d_rng, (int64_t)sizeof(rpp::MT), d_ox, d_oy, d_osz, m, max_iter,
+                         d_out, out_stride, d_on, d_st};
+      hipLaunchKernelGGL(rpps::smooth_kernel, dim3(n_jobs), dim3(64), 0, 0, a, n_jobs);
+      ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess &&
+           hipMemcpy(out_xy, d_out, sizeof(double) * 2 * (size_t)out_stride * n_jobs, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(out_n, d_on, sizeof(int32_t) * n_jobs, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(st.data(), d_st, sizeof(int32_t) * n_jobs, hipMemcpyDeviceToHost) == hipSuccess &&
+           hipMemcpy(rng.data(), d_rng, sizeof(rpp::MT) * n_jobs, hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (!ok) rc = RRTX_E_HIP;
+  }
+  for (void* q : {(void*)d_in, (void*)d_out, (void*)d_ox, (void*)d_oy, (void*)d_osz, (void*)d_n, (void*)d_on, (void*)d_st,
+                  (void*)d_rng})
+    if (q) hipFree(q);
+  if (rc != RRTX_OK) return rc;
+  for (int j = 0; j < n_jobs; j++) {
+    memcpy(mt_words + (size_t)j * 624, rng[j].mt, 624 * 4);
+    mt_pos[j] = rng[j].pos;
+    status[j] = st[j];
+  }
+  return smooth_status_rc(st, nullptr);
+}
+
+int rrtx_smooth_planned(rrtx_handle* h, int32_t max_iter) {
+  if (!h || max_iter < 0) return RRTX_E_INVALID;
+  if (!h->planned || (h->p.algo != RRTX_ALGO_RRT && h->p.algo != RRTX_ALGO_RRT_STAR)) return RRTX_E_STATE;
+  if (h->m > rpps::MOB) return RRTX_E_INVALID;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int B = h->n_inst;
+  int rc;
+  if (!h->sm_osz) {
+    h->sm_stride = rpps::PC;
+    if ((rc = dalloc(h, &h->sm_osz, rppk::MAX_OBS))) return rc;
+    if ((rc = dalloc(h, &h->sm_xy, (size_t)2 * h->sm_stride * B))) return rc;
+    if ((rc = dalloc(h, &h->sm_n, B))) return rc;
+    if ((rc = dalloc(h, &h->sm_status, B))) return rc;
+  }
+  std::vector<double> osz(rppk::MAX_OBS, 0.0);
+  for (int k = 0; k < h->m; k++) osz[k] = h->obst[3 * k + 2];
+  HIPCHK(h, hipMemcpy(h->sm_osz, osz.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice));
+  Ctx& c = h->c;
+  rpps::SmoothArgs a{c.path_xy, c.path_cap, &c.inst[0].path_n, (int64_t)(sizeof(Inst) / sizeof(int32_t)),
+                     &c.inst[0].rng, (int64_t)sizeof(Inst), c.ox, c.oy, h->sm_osz, h->m, max_iter,
+                     h->sm_xy, h->sm_stride, h->sm_n, h->sm_status};
+  hipLaunchKernelGGL(rpps::smooth_kernel, dim3(B), dim3(64), 0, h->stream, a, B);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  std::vector<int32_t> st(B);
+  HIPCHK(h, hipMemcpy(st.data(), h->sm_status, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+  h->smoothed = true;
+  return smooth_status_rc(st, &h->err);
+}
+
+int rrtx_get_smoothed_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_points, int32_t* n_out) {
+  if (!h || !n_out || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (!h->smoothed) return RRTX_E_STATE;
+  int32_t n = 0;
+  HIPCHK(h, hipMemcpy(&n, h->sm_n + instance, sizeof(n), hipMemcpyDeviceToHost));
+  *n_out = n;
+  if (!xy || n == 0) return RRTX_OK;
+  if (cap_points < n) return RRTX_E_CAPACITY;
+  HIPCHK(h, hipMemcpy(xy, h->sm_xy + (size_t)2 * h->sm_stride * instance, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
   return RRTX_OK;
 }
 

@@ -468,6 +468,18 @@ class RRTDubins(RRTStarDubins):
             self.sobol_inter_ = h.get_sobol_index(0)
 
 
+def path_smoothing(path, max_iter, obstacle_list, device=0):
+    """Drop-in for rrt_04's module function `path_smoothing(path, max_iter, obstacle_list)` (:1447-1479): random
+    shortcutting of the path `planning()` returned, drawing from CPython's global `random` stream (left exactly where
+    the reference would leave it).  Runs on the GPU through the C ABI; see `Handle.smooth_planned` for batches."""
+    st = random.getstate()
+    out, states, _ = _abi.smooth_paths([path], max_iter, obstacle_list, [(np.array(st[1][:624], dtype=np.uint32), st[1][624])],
+                                       device=device)
+    w, pos = states[0]
+    random.setstate((st[0], tuple(int(v) for v in w) + (int(pos),), st[2]))
+    return [[float(a), float(b)] for a, b in out[0]]
+
+
 def bitstar_rotation(start_xy, goal_xy):
     """cMin and C of rrt_08:189-202, computed with numpy exactly as the reference does."""
     c_min = math.hypot(start_xy[0] - goal_xy[0], start_xy[1] - goal_xy[1]) / 1.5

@@ -475,3 +475,56 @@ def test_bitstar_host_class_drop_in(gpu):
     path = b.plan(animation=False)
     assert len(path) == 9 and np.array_equal(np.array(path), g["path"])
     assert random.getstate()[1][624] == int(g["rng_pos_after"])
+
+
+# ------------------------------------------------------------------------------------------------ path smoothing
+def test_gpu_path_smoothing_matches_reference_golden(gpu):
+    """path_smoothing (rrt_04:1447-1479) through rrtx_smooth_paths, all goldens as one batch per max_iter: smoothed
+    polyline and MT19937 state after the call, bit for bit."""
+    import rrt_amd
+    gs = [util.load_golden(p) for p in util.golden_files("smooth")]
+    assert len(gs) >= 6
+    for it in sorted({int(g["max_iter"]) for g in gs}):
+        for obst_key in sorted({g["obstacles"].tobytes() for g in gs if int(g["max_iter"]) == it}):
+            grp = [g for g in gs if int(g["max_iter"]) == it and g["obstacles"].tobytes() == obst_key]
+            out, states, st = rrt_amd._abi.smooth_paths([g["path_in"] for g in grp], it, grp[0]["obstacles"],
+                                                        [(g["rng_mt_before"], int(g["rng_pos_before"])) for g in grp])
+            for g, o, (w, pos) in zip(grp, out, states):
+                assert np.array_equal(o, g["smoothed"]), g["name"]
+                assert pos == int(g["rng_pos_after"]) and int(w[0]) == int(g["rng_word0_after"]), g["name"]
+
+
+def test_driver_sequence_planning_then_smoothing(gpu):
+    """The reference driver's sequence (rrt_04:1548-1559): random.seed -> RRT(...).planning() -> path_smoothing(path, 1000,
+    obstacleList), all on the global random stream; and the same as a device-resident batch (rrtx_smooth_planned)."""
+    import random
+    import rrt_amd
+    obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)]
+    seeds = [1234, 5, 7]
+    gold = {sd: util.load_golden(util.GOLDEN + "/smooth_drv_s%d.npz" % sd) for sd in seeds}
+    for sd in seeds:
+        g = gold[sd]
+        random.seed(sd)
+        rrt = rrt_amd.RRTStar(start=[0, 0], goal=[6.0, 10.0], obstacle_list=obst, rand_area=[-2, 15], expand_dis=1.0,
+                              path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=[0, 10, 0, 14],
+                              robot_radius=0.6, sobol_sampler=False, connect_circle_dist=50.0, search_until_max_iter=True)
+        path = rrt.planning(animation=False)
+        assert np.array_equal(np.array(path), g["path_in"])
+        sm = rrt_amd.path_smoothing(path, 1000, obst)
+        assert np.array_equal(np.array(sm), g["smoothed"])
+        st = random.getstate()
+        assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+    A = rrt_amd._abi
+    h = A.Handle(A.ALGO_RRT_STAR, [0, 0], [6.0, 10.0], [-2, 15], 1.0, 0.1, 5, 500, play_area=[0, 10, 0, 14],
+                 robot_radius=0.6, connect_circle_dist=50.0, search_until_max_iter=True, n_instances=len(seeds))
+    try:
+        h.set_obstacles(obst)
+        h.seed_instances(seeds)
+        h.plan()
+        h.smooth_planned(1000)
+        for i, sd in enumerate(seeds):
+            assert np.array_equal(h.get_smoothed_path(i), gold[sd]["smoothed"])
+            st = h.get_rng_state(i)
+            assert st[1][624] == int(gold[sd]["rng_pos_after"]) and st[1][0] == int(gold[sd]["rng_word0_after"])
+    finally:
+        h.close()

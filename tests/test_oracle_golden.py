@@ -161,3 +161,17 @@ def test_bitstar_spot_value_survey_section10():
     p = g["path"]
     assert len(p) == 9 and len(g["vertex_ids"]) == 80 and int(g["n_edges"]) == 79
     assert np.allclose(p[:4], [[-1.0, 0.0], [-0.64, 1.16], [-0.28, 2.73], [-0.92, 4.49]], atol=1e-12)
+
+
+@pytest.mark.parametrize("path", util.golden_files("smooth"), ids=lambda p: p.split("/")[-1][:-4])
+def test_path_smoothing_oracle_matches_reference_golden(path):
+    """path_smoothing (rrt_04:1447-1479) after planning, on the stream planning() left: smoothed polyline and RNG state."""
+    import oracle
+    g = util.load_golden(path)
+    rng = oracle.MT()
+    for i in range(624):
+        rng.mt[i] = int(g["rng_mt_before"][i])
+    rng.pos = int(g["rng_pos_before"])
+    sm = oracle.path_smoothing(g["path_in"], int(g["max_iter"]), g["obstacles"], rng)
+    assert np.array_equal(sm, g["smoothed"])
+    assert rng.pos == int(g["rng_pos_after"]) and rng.mt[0] == int(g["rng_word0_after"])
