@@ -163,6 +163,13 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
   int32_t* parent = c.parent + off;
   int32_t* hits = c.hits + off;
   double* pathbuf = c.path_xy + (int64_t)inst * c.path_cap * 2;
+  // f32 mirror of the coordinates for the two streaming passes (see scan_nearest_f32): valid while every coordinate
+  // and query stays below the magnitude the margin c.f32_m was derived from; informed samples are not clipped to the
+  // sampling square (rrt_07:1145-1159), so an instance that leaves it switches to the f64 passes for good
+  float* __restrict__ xf = c.xf ? c.xf + off : nullptr;
+  float* __restrict__ yf = c.xf ? c.yf + off : nullptr;
+  const double fm = c.f32_m, fmax = c.f32_m * 1048576.0;   // margin = 2^-20 * fmax
+  int f32_ok = (c.xf != nullptr) && (I->first_goal != -3);
 
   for (int i = tid; i < 624; i += TPB) sh.rng.mt[i] = I->rng.mt[i];
   for (int i = tid; i < c.m; i += TPB) {
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
   const double gx = I->goal[0], gy = I->goal[1], sx0 = I->start[0], sy0 = I->start[1];
   const double E = c.expand_dis;
   rpp::Sobol sob = I->sobol;
-  int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_sn = 0, s_ab = 0, s_ex = 0;
+  int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_sn = 0, s_ab = 0, s_ab2 = 0, s_ex = 0;
   int stop = 0;
 
   for (int step = 0; step < iters && it < c.max_iter && !stop; step++, it++) {
@@ -226,9 +233,27 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     // ---------------- nearest :1210-1214
     int ni;
     double gbest, gsecond;
-    rppk::scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
+    const bool q_ok = f32_ok && rpp::dabs(rx) <= fmax && rpp::dabs(ry) <= fmax;
+    bool nearest_done = false;
+    if (q_ok) {
+      int fi;
+      double fb, fs;
+      rppk::scan_nearest_f32(xf, yf, n, (float)rx, (float)ry, sh, fi, fb, fs);
+      s_ab += 8 * (int64_t)n;
+      if (__builtin_sqrt(fs) - __builtin_sqrt(fb) > 2.0 * fm) {
+        ni = fi;
+        gbest = 1.0;
+        gsecond = rpp::dinf();
+        nearest_done = true;
+      }
+    }
+    if (!nearest_done) {
+      rppk::scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
+      s_ab += 16 * (int64_t)n;
+    }
     s_sn += n;
-    s_ab += 16 * (int64_t)n + 24 * (int64_t)c.m;
+    s_ab += 24 * (int64_t)c.m;
+    s_ab2 += 16 * (int64_t)n + 24 * (int64_t)c.m;
     if (gbest != 0.0 && gsecond <= gbest * (1.0 + FILTER_EPS)) {
       s_ex++;
       const int kraw = rppk::scan_hits(x, y, n, rx, ry, gbest * (1.0 + FILTER_EPS), hits, sh);
@@ -276,14 +301,23 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     if (accepted) {
       // ---------------- find_near_nodes :1137-1143  (n_node = len(node_list), radius not capped)
       const double r2 = c.r2tab[n];
-      const int kraw = rppk::scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
+      int kraw;
+      if (f32_ok && rpp::dabs(nx) <= fmax && rpp::dabs(ny) <= fmax) {
+        const double rr = __builtin_sqrt(r2) + fm;   // ball radius r + m in the f32 metric, rounded up
+        kraw = rppk::scan_hits_f32(xf, yf, n, (float)nx, (float)ny, (float)(rr * rr * (1.0 + 1e-6)), hits, sh);
+        s_ab += 8 * (int64_t)n + 16 * (int64_t)kraw;
+      } else {
+        kraw = rppk::scan_hits(x, y, n, nx, ny, r2 * (1.0 + FILTER_EPS), hits, sh);
+        s_ab += 16 * (int64_t)n;
+      }
       s_sn += n;
       build_candidates_i(x, y, cost, nx, ny, r2, hits, kraw, sh);
       const int nu = sh.nu, nvalid = sh.nvalid;
       nnear = nu;
       s_nh += nvalid;
       s_nu += nu;
-      s_ab += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
+      s_ab += 48 * (int64_t)nu + 28;
+      s_ab2 += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
       // ---------------- choose_parent :1110-1135 : (d, theta, end point) per candidate, then candidate x obstacle
       for (int e = tid; e < nu; e += TPB) {
         const double dx = nx - sh.ux[e], dy = ny - sh.uy[e];
@@ -320,10 +354,15 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
         __syncthreads();
       }
       const double ncost = sh.ncost;
+      if (rpp::dabs(nx) > fmax || rpp::dabs(ny) > fmax) f32_ok = 0;   // outside the magnitude the margin covers
       // ---------------- append :1091, rewire :1232-1246 (independent per candidate, same (theta, d) as above)
       if (tid == 0) {
         x[n] = nx;
         y[n] = ny;
+        if (xf) {
+          xf[n] = (float)nx;
+          yf[n] = (float)ny;
+        }
         cost[n] = ncost;
         parent[n] = sh.npar;
         sh.nrw = 0;
@@ -425,6 +464,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     I->sobol = sob;
     I->n = n;
     I->it = it;
+    if (!f32_ok) I->first_goal = -3;
     cbest_io[inst] = sh.cbest;
     if (it >= c.max_iter || sh.overflow) I->status |= 1;
     if (sh.overflow) I->status |= 4;
@@ -436,7 +476,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     I->rewires += s_rw;
     I->scan_nodes += s_sn;
     I->alg_bytes += s_ab;
-    I->alg_bytes2 += s_ab;
+    I->alg_bytes2 += s_ab2;
     I->exact_rescans += s_ex;
     c.results[inst].n_nodes = n;
     c.results[inst].status = I->status;

@@ -274,6 +274,100 @@ __device__ __forceinline__ int scan_hits(const double* __restrict__ x, const dou
 }
 
 // ---------------------------------------------------------------------------
+// The same two passes over the f32 mirror xf[], yf[] (8 bytes per node; lane -> 4 adjacent nodes).  Distances from
+// the mirror differ from the true ones by less than Ctx::f32_m, so the callers treat the results as candidates:
+// the nearest index is final only if the runner-up is more than 2m further (distance metric), threshold hits are
+// re-tested from the f64 coordinates.  See scan2f in rrt_star_v2_body.inc for the bound.
+typedef float v4f_k __attribute__((ext_vector_type(4)));
+constexpr int WAVE_STRIDE_F = 256 * UNROLL;
+template <class SH>
+__device__ __forceinline__ void scan_nearest_f32(const float* __restrict__ xf, const float* __restrict__ yf, int n,
+                                                 float qx, float qy, SH& sh, int& ni, double& gbest, double& gsecond) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE_F);
+  const int ws = w * per;
+  const int we = ws + per;
+  float best = __builtin_inff(), second = __builtin_inff();
+  int bidx = 0x7fffffff;
+  for (int base = ws; base < we && base < n; base += WAVE_STRIDE_F) {
+    v4f_k xv[UNROLL], yv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 256 + lane * 4;
+      xv[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f_k*>(xf + i0));
+      yv[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f_k*>(yf + i0));
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 256 + lane * 4;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float dx = xv[u][j] - qx, dy = yv[u][j] - qy;
+        const float d = __builtin_fmaf(dx, dx, dy * dy);
+        const bool lt = d < best;
+        second = lt ? best : (d < second ? d : second);
+        bidx = lt ? i0 + j : bidx;
+        best = lt ? d : best;
+      }
+    }
+  }
+  block_argmin((double)best, bidx, (double)second, sh, gbest, ni, gsecond);
+}
+template <class SH>
+__device__ __forceinline__ int scan_hits_f32(const float* __restrict__ xf, const float* __restrict__ yf, int n, float qx,
+                                             float qy, float thr, int32_t* __restrict__ hits, SH& sh) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE_F);
+  const int ws = w * per;
+  const int we = ws + per;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int cnt = 0;
+  for (int base = ws; base < we && base < n; base += WAVE_STRIDE_F) {
+    v4f_k xv[UNROLL], yv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 256 + lane * 4;
+      xv[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f_k*>(xf + i0));
+      yv[u] = __builtin_nontemporal_load(reinterpret_cast<const v4f_k*>(yf + i0));
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+      const int i0 = base + u * 256 + lane * 4;
+      bool hh[4];
+      uint64_t mm[4], any = 0ull;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float dx = xv[u][j] - qx, dy = yv[u][j] - qy;
+        hh[j] = __builtin_fmaf(dx, dx, dy * dy) <= thr;
+        mm[j] = __ballot(hh[j]);
+        any |= mm[j];
+      }
+      if (any != 0ull) {
+        int pos = cnt, tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          pos += __popcll(mm[j] & lt_mask);
+          tot += __popcll(mm[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (hh[j]) hits[ws + pos++] = i0 + j;
+        cnt += tot;
+      }
+    }
+  }
+  if (lane == 0) {
+    sh.wave_cnt[w] = cnt;
+    sh.wave_start[w] = ws;
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
+  return total;
+}
+
+// ---------------------------------------------------------------------------
 // Fused pass: ONE stream over x[0..n), y[0..n) serves two queries -- the near-ball
 // threshold scan about (qx,qy) of THIS iteration (rrt_04:1335-1337) and the
 // nearest-node argmin about (sx,sy), the sample of the NEXT iteration

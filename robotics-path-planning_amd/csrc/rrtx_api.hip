@@ -157,10 +157,12 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if ((rc = dalloc(h, &c.prev_sib, tot))) return rc;
   if ((rc = dalloc(h, &c.hits, tot))) return rc;
   if ((rc = dalloc(h, &c.stack, tot))) return rc;
-  if (p->algo == RRTX_ALGO_RRT_STAR && p->search_until_max_iter) {
-    // float mirror of the coordinates for the prefiltered streaming pass (rrt_star_v2_body.inc)
+  if ((p->algo == RRTX_ALGO_RRT_STAR && p->search_until_max_iter) || p->algo == RRTX_ALGO_INFORMED) {
+    // float mirror of the coordinates for the prefiltered streaming passes (rrt_star_v2_body.inc, rrt_informed.hip.h)
     if ((rc = dalloc(h, &c.xf, tot))) return rc;
     if ((rc = dalloc(h, &c.yf, tot))) return rc;
+  }
+  if (p->algo == RRTX_ALGO_RRT_STAR && p->search_until_max_iter) {
     if ((rc = dalloc(h, &c.elen, tot))) return rc;   // cached parent-edge lengths (cost propagation)
   }
   if ((rc = dalloc(h, &c.results, h->n_inst))) return rc;
@@ -374,6 +376,21 @@ int rrtx_plan(rrtx_handle* h) {
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  // f32-mirror margin = 2^-20 * the largest coordinate magnitude a node or sample is assumed to have (see scan2f);
+  // rrt_07's informed samples are not clipped to the sampling square, so twice that (the kernel checks and falls back)
+  {
+    double mag = fabs(c.rand_min) > fabs(c.rand_max) ? fabs(c.rand_min) : fabs(c.rand_max);
+    for (int i = 0; i < B; i++) {
+      const Inst& I = h->host_inst[i];
+      const double v[4] = {I.start[0], I.start[1], I.goal[0], I.goal[1]};
+      for (double q : v)
+        if (fabs(q) > mag) mag = fabs(q);
+    }
+    if (c.algo == RRTX_ALGO_INFORMED) mag *= 2.0;
+    c.f32_m = ldexp(mag > 1.0 ? mag : 1.0, -20);
+  }
+  if (const char* e = getenv("RRTX_F32"))
+    if (atoi(e) == 0 && c.algo == RRTX_ALGO_INFORMED) c.xf = c.yf = nullptr;   // informed kernel: f64 passes only
   double kms = 0.0;
   int64_t launches = 0;
   std::vector<Result> res(B);
@@ -426,16 +443,6 @@ int rrtx_plan(rrtx_handle* h) {
     // magnitude any node or sample can have (see scan2f)
     bool f32 = c.xf != nullptr;
     if (const char* e = getenv("RRTX_F32")) f32 = f32 && atoi(e) != 0;
-    {
-      double mag = fabs(c.rand_min) > fabs(c.rand_max) ? fabs(c.rand_min) : fabs(c.rand_max);
-      for (int i = 0; i < B; i++) {
-        const Inst& I = h->host_inst[i];
-        const double v[4] = {I.start[0], I.start[1], I.goal[0], I.goal[1]};
-        for (double q : v)
-          if (fabs(q) > mag) mag = fabs(q);
-      }
-      c.f32_m = ldexp(mag > 1.0 ? mag : 1.0, -20);
-    }
     for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->chunk_iters) {
       HIPCHK(h, hipEventRecord(h->ev0, h->stream));
       if (tpb == 64) {
