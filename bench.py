@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--obstacles", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations (the headline metric); c3: rrt_07 Informed RRT* "
-                         "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 768 instances; "
+                         "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 1024 instances; "
                          "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1536 instances; "
                          "c4: rrt_08 BIT*, driver constants, per-instance start/goal (SURVEY 8d), 80 iterations")
     ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
@@ -69,7 +69,7 @@ def main():
         if "--max-iter" not in sys.argv:
             a.max_iter = 20000
         if "--instances" not in sys.argv:
-            a.instances = 768
+            a.instances = 1024     # 4 workgroups of 256 threads per CU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -33,8 +33,11 @@ struct ShI {
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   int32_t uidx[NUI], ufree[NUI];
-  double uval[NUI], ux[NUI], uy[NUI], ucost[NUI], ud[NUI], uex[NUI], uey[NUI];
-  double cval[TPB];
+  // uval (d**2 of a candidate, duplicate collapse) and cval (per-thread scratch of the same phase) are dead before
+  // choose_parent writes ud / uex: they share storage, which keeps the block under 40 KB (4 workgroups per CU)
+  union { double uval[NUI]; double ud[NUI]; };
+  union { double cval[TPB]; double uex[NUI]; };
+  double ux[NUI], uy[NUI], ucost[NUI], uey[NUI];
   int32_t cflag[TPB];
   double red_best[NW], red_second[NW];
   int32_t red_idx[NW], wave_cnt[NW], wave_start[NW];
@@ -150,7 +153,7 @@ struct InformedArgs {
   double c_min2;
 };
 
-__global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArgs ia, double* cbest_io, int iters) {
+__global__ __launch_bounds__(TPB, 4) void rrt_informed_kernel(Ctx c, InformedArgs ia, double* cbest_io, int iters) {
   __shared__ ShI sh;
   const int inst = blockIdx.x;
   const int tid = threadIdx.x;
@@ -189,9 +192,11 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
   rpp::Sobol sob = I->sobol;
   int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_sn = 0, s_ab = 0, s_ab2 = 0, s_ex = 0;
   int stop = 0;
+  PH_DECL
 
   for (int step = 0; step < iters && it < c.max_iter && !stop; step++, it++) {
     s_iter++;
+    PH(15);
     // ---------------- informed_sample :1145-1159
     if (tid == 0) {
       double rx, ry;
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     __syncthreads();
     const double rx = sh.rx, ry = sh.ry;
 
+    PH(0);
     // ---------------- nearest :1210-1214
     int ni;
     double gbest, gsecond;
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
       rppk::block_argmin(best, bidx, second, sh, gb2, ni, gs2);
     }
 
+    PH(1);
     // ---------------- steer :1080-1083 / get_new_node :1216-1224, extension edge :1085
     if (tid == 0) {
       const double qx = x[ni], qy = y[ni];
@@ -299,6 +306,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     int nnear = -1;
 
     if (accepted) {
+      PH(2);
       // ---------------- find_near_nodes :1137-1143  (n_node = len(node_list), radius not capped)
       const double r2 = c.r2tab[n];
       int kraw;
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
       s_nu += nu;
       s_ab += 48 * (int64_t)nu + 28;
       s_ab2 += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
+      PH(4);
       // ---------------- choose_parent :1110-1135 : (d, theta, end point) per candidate, then candidate x obstacle
       for (int e = tid; e < nu; e += TPB) {
         const double dx = nx - sh.ux[e], dy = ny - sh.uy[e];
@@ -355,6 +364,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
       }
       const double ncost = sh.ncost;
       if (rpp::dabs(nx) > fmax || rpp::dabs(ny) > fmax) f32_ok = 0;   // outside the magnitude the margin covers
+      PH(6);
       // ---------------- append :1091, rewire :1232-1246 (independent per candidate, same (theta, d) as above)
       if (tid == 0) {
         x[n] = nx;
@@ -388,6 +398,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
       s_rw += sh.nrw;
       s_eu += sh.nvalid - nvalid;
       s_er += sh.nvalid - nvalid;
+      PH(9);
       // ---------------- goal bookkeeping :1094-1103
       if (tid == 0) {
         sh.flag = (rpp::py_hypot(nx - gx, ny - gy) < E) ? 1 : 0;   // is_near_goal :1226-1230 (strict)
@@ -465,6 +476,7 @@ __global__ __launch_bounds__(TPB, 3) void rrt_informed_kernel(Ctx c, InformedArg
     I->n = n;
     I->it = it;
     if (!f32_ok) I->first_goal = -3;
+    PH_STORE(I);
     cbest_io[inst] = sh.cbest;
     if (it >= c.max_iter || sh.overflow) I->status |= 1;
     if (sh.overflow) I->status |= 4;
