@@ -186,8 +186,9 @@ def main():
         traffic_note = None
         # PMC traffic of the same workload and kernel variant, measured in separate rocprofv3 --pmc passes
         # (tools/profile_headline.sh -> profiles/*_traffic.json)
-        variant = "f64" if os.environ.get("RRTX_F32", "1") == "0" else "f32_mirror"
-        for tf in ("r1_t64_traffic.json", "r1_f32_traffic.json", "r1_traffic.json"):
+        variant = "f64" if os.environ.get("RRTX_F32", "1") == "0" else (
+            "f32_mirror" if os.environ.get("RRTX_Q16", "1") == "0" else "q16_mirror")
+        for tf in ("r1_q16_traffic.json", "r1_t64_traffic.json", "r1_f32_traffic.json", "r1_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             except Exception:  # noqa: BLE001
@@ -227,12 +228,13 @@ def main():
                          "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
                          "traffic_note": traffic_note,
                          "survey_8d_two_scan_GBps": achieved_2s, "survey_8d_two_scan_frac": achieved_2s / 8000.0,
-                         "note": "achieved = single-pass algorithmic bytes (8*n per iteration from the f32 coordinate mirror, 16*n with RRTX_F32=0: the near pass of "
+                         "note": "achieved = single-pass algorithmic bytes (4*n per iteration from the 16-bit coordinate mirror, 8*n with RRTX_Q16=0 (f32 mirror), 16*n with RRTX_F32=0: the near pass of "
                                  "iteration i also answers the nearest query of i+1) / kernel time; "
                                  "survey_8d_two_scan_* applies SURVEY 8(d)'s two-scan formula (32*n) to the same run",
                          "kernel_ms_per_step": kernel_ms / max(steps_done, 1)},
             "steps_requested": a.steps, "warmup_max_iter": a.warmup_max_iter or a.max_iter,
             "near_unique_max": stats.get("near_unique_max"), "f32_fallbacks_last_step": stats.get("f32_fallbacks"),
+            "q16_fallbacks_last_step": stats.get("q16_fallbacks"),
             "exact_rescans_last_step": stats.get("exact_rescans"),
         }
         if not a.no_cpu_baseline:

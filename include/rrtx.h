@@ -100,7 +100,8 @@ typedef struct rrtx_stats {
   int64_t algorithmic_bytes_two_scan; /* SURVEY.md 8d formula as written: 32*n + 48*k + 24*M + 28 per accepted iteration */
   int64_t near_unique_max;   /* largest number of distinct near candidates any iteration of any instance produced */
   int64_t f32_fallbacks;     /* nearest queries the f32-mirror pass could not decide (repeated with the f64 pass) */
-  int64_t reserved[5];
+  int64_t q16_fallbacks;     /* nearest queries the 16-bit first stage could not decide (repeated with the f32 pass) */
+  int64_t reserved[4];
 } rrtx_stats;
 
 typedef struct rrtx_handle rrtx_handle;

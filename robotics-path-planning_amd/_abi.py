@@ -46,7 +46,8 @@ class Stats(C.Structure):
                 ("propagated", C.c_int64), ("scan_nodes", C.c_int64), ("algorithmic_bytes", C.c_int64),
                 ("exact_rescans", C.c_int64), ("total_nodes", C.c_int64), ("launches", C.c_int64),
                 ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("algorithmic_bytes_two_scan", C.c_int64),
-                ("near_unique_max", C.c_int64), ("f32_fallbacks", C.c_int64), ("reserved", C.c_int64 * 5)]
+                ("near_unique_max", C.c_int64), ("f32_fallbacks", C.c_int64), ("q16_fallbacks", C.c_int64),
+                ("reserved", C.c_int64 * 4)]
 
 
 class RrtxError(RuntimeError):

@@ -58,7 +58,7 @@ struct Inst {  // persistent per-instance state (global memory)
   int32_t n, it, status, goal_node, path_n;
   int32_t first_goal;   // lowest index of a node lying exactly on the goal (-1 none yet, -2 unknown); f32-mirror path only
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
-      exact_rescans, alg_bytes2, nu_max, f32_fallbacks;
+      exact_rescans, alg_bytes2, nu_max, f32_fallbacks, q16_fallbacks;
   int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
 };
 
@@ -92,10 +92,22 @@ struct Ctx {
   // f32 mirror of x[], y[] (prefilter of the streaming pass, rrt_star_v2_body.inc) and its distance margin
   float *xf, *yf;
   double f32_m;
+  // 16-bit fixed-point mirror, 4 bytes per node: (x16 | y16 << 16), q = rint((coord - q_lo) * q_inv); first stage of
+  // the rrt_04 iteration kernel's streaming pass (scan2q); q_m = distance margin of that stage
+  uint32_t* xq;
+  double q_lo, q_inv, q_step, q_m;
   // elen[i] = hypot(node i - its parent), exactly the value calc_new_cost (rrt_04:1375-1377) would compute now;
   // kept by the v2 kernel so cost propagation needs no coordinates and no hypot
   double* elen;
 };
+
+// 16-bit mirror entry of a point (Ctx::xq)
+__device__ __forceinline__ uint32_t quant16(const Ctx& c, double px, double py) {
+  double qx = __builtin_rint((px - c.q_lo) * c.q_inv), qy = __builtin_rint((py - c.q_lo) * c.q_inv);
+  qx = qx < 0.0 ? 0.0 : (qx > 65535.0 ? 65535.0 : qx);
+  qy = qy < 0.0 ? 0.0 : (qy > 65535.0 ? 65535.0 : qy);
+  return (uint32_t)qx | ((uint32_t)qy << 16);
+}
 
 struct Sh {
   static constexpr int kNU = NU_MAX;
@@ -1241,6 +1253,7 @@ __global__ void rrt_init_kernel(Ctx c) {
       c.xf[off + i] = __builtin_inff();
       c.yf[off + i] = __builtin_inff();
     }
+    if (c.xq) c.xq[off + i] = 0xffffffffu;
   }
 }
 __global__ void rrt_root_kernel(Ctx c, int ninst) {
@@ -1254,6 +1267,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
     c.xf[off] = (float)I->start[0];
     c.yf[off] = (float)I->start[1];
   }
+  if (c.xq) c.xq[off] = quant16(c, I->start[0], I->start[1]);
   I->first_goal = -1;
   if (c.elen) c.elen[off] = 0.0;
   c.cost[off] = 0.0;
@@ -1270,7 +1284,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   I->sobol.lastq[0] = I->sobol.lastq[1] = I->sobol.lastq[2] = 0;
   I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
   I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = I->alg_bytes2 = 0;
-  I->nu_max = I->f32_fallbacks = 0;
+  I->nu_max = I->f32_fallbacks = I->q16_fallbacks = 0;
   for (int k = 0; k < 16; k++) I->phase[k] = 0;
   c.results[inst].path_cost = 0.0;
   c.results[inst].n_nodes = 1;

@@ -164,6 +164,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   }
   if (p->algo == RRTX_ALGO_RRT_STAR && p->search_until_max_iter) {
     if ((rc = dalloc(h, &c.elen, tot))) return rc;   // cached parent-edge lengths (cost propagation)
+    if ((rc = dalloc(h, &c.xq, tot))) return rc;     // 16-bit mirror (first stage of the streaming pass)
   }
   if ((rc = dalloc(h, &c.results, h->n_inst))) return rc;
   c.path_cap = (int32_t)(cap + 1 < 8192 ? cap + 1 : 8192);
@@ -368,14 +369,6 @@ int rrtx_plan(rrtx_handle* h) {
   HIPCHK(h, hipSetDevice(h->device));
   Ctx& c = h->c;
   const int B = h->n_inst;
-  HIPCHK(h, hipMemcpyAsync(c.inst, h->host_inst.data(), sizeof(Inst) * B, hipMemcpyHostToDevice, h->stream));
-  {
-    dim3 g(64, B);
-    hipLaunchKernelGGL(rppk::rrt_init_kernel, g, dim3(256), 0, h->stream, c);
-    hipLaunchKernelGGL(rppk::rrt_root_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, c, B);
-  }
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipStreamSynchronize(h->stream));
   // f32-mirror margin = 2^-20 * the largest coordinate magnitude a node or sample is assumed to have (see scan2f);
   // rrt_07's informed samples are not clipped to the sampling square, so twice that (the kernel checks and falls back)
   {
@@ -388,9 +381,36 @@ int rrtx_plan(rrtx_handle* h) {
     }
     if (c.algo == RRTX_ALGO_INFORMED) mag *= 2.0;
     c.f32_m = ldexp(mag > 1.0 ? mag : 1.0, -20);
+    // 16-bit mirror: the square [lo, hi]^2 that holds every node and sample (sampling square, starts, goals; nodes are
+    // convex combinations of those).  Quantisation error <= step/2 per coordinate -> distance error <= step/sqrt(2)
+    // (+ f32 arithmetic ~1e-5 * range); margin = one step.
+    double lo = c.rand_min < c.rand_max ? c.rand_min : c.rand_max, hi = c.rand_min < c.rand_max ? c.rand_max : c.rand_min;
+    for (int i = 0; i < B; i++) {
+      const Inst& I = h->host_inst[i];
+      const double v[4] = {I.start[0], I.start[1], I.goal[0], I.goal[1]};
+      for (double q : v) {
+        if (q < lo) lo = q;
+        if (q > hi) hi = q;
+      }
+    }
+    const double range = hi - lo > 1e-9 ? hi - lo : 1.0;
+    c.q_lo = lo;
+    c.q_step = range / 65535.0;
+    c.q_inv = 65535.0 / range;
+    c.q_m = c.q_step;
   }
   if (const char* e = getenv("RRTX_F32"))
     if (atoi(e) == 0 && c.algo == RRTX_ALGO_INFORMED) c.xf = c.yf = nullptr;   // informed kernel: f64 passes only
+  if (const char* e = getenv("RRTX_Q16"))
+    if (atoi(e) == 0) c.xq = nullptr;   // rrt_04 kernel: no 16-bit first stage (f32 mirror first)
+  HIPCHK(h, hipMemcpyAsync(c.inst, h->host_inst.data(), sizeof(Inst) * B, hipMemcpyHostToDevice, h->stream));
+  {
+    dim3 g(64, B);
+    hipLaunchKernelGGL(rppk::rrt_init_kernel, g, dim3(256), 0, h->stream, c);
+    hipLaunchKernelGGL(rppk::rrt_root_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, c, B);
+  }
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   double kms = 0.0;
   int64_t launches = 0;
   std::vector<Result> res(B);
@@ -531,6 +551,7 @@ int rrtx_plan(rrtx_handle* h) {
     s.algorithmic_bytes_two_scan += I.alg_bytes2;
     s.total_nodes += I.n;
     s.f32_fallbacks += I.f32_fallbacks;
+    s.q16_fallbacks += I.q16_fallbacks;
     if (I.nu_max > s.near_unique_max) s.near_unique_max = I.nu_max;
     if (I.status & RRTX_ST_OVERFLOW) overflow = true;
     for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];

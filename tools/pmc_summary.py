@@ -24,7 +24,7 @@ ap.add_argument("tag")
 ap.add_argument("--instances", type=int, default=4096)
 ap.add_argument("--max-iter", type=int, default=105000)
 ap.add_argument("--obstacles", type=int, default=50)
-ap.add_argument("--variant", default="f32_mirror")
+ap.add_argument("--variant", default="q16_mirror")
 ap.add_argument("--alg-bytes", type=float, default=None)
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
