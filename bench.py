@@ -237,7 +237,7 @@ def main():
             "q16_fallbacks_last_step": stats.get("q16_fallbacks"),
             "exact_rescans_last_step": stats.get("exact_rescans"),
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and ngpu == 1:   # the CPU baseline is reported by the single-GPU run only
             import oracle
             tc = time.perf_counter()
             if c5:
@@ -347,7 +347,7 @@ def bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu):
                              "note": "instance-parallel sequential search (one lane per instance): latency-bound, "
                                      "no streaming pass to price against HBM",
                              "kernel_ms_per_step": kernel_ms / max(a.steps, 1)}}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and ngpu == 1:
             import oracle
             nsmp = min(B, 48)
             tc = time.perf_counter()
