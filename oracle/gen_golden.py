@@ -340,7 +340,7 @@ def main05(only=""):
     obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)]       # rrt_05:1804-1806
     drv = dict(obstacles=obst, start=[0.0, 0.0, float(np.deg2rad(0.0))], goal=[10.0, 10.0, float(np.deg2rad(0.0))],
                rand_area=[-2, 15])
-    for seed, it in ((42, 150), (42, 500), (1, 300), (2, 300), (7, 400)):
+    for seed, it in ((42, 150), (42, 500), (1, 300), (2, 300), (7, 400), (374, 3000)):   # 374: a node rewired twice in one iteration
         n = "rrt05_drv_s%d_it%d" % (seed, it)
         if n.startswith(only):
             run_rrt05(m05, n, max_iter=it, seed=seed, **drv)

@@ -245,6 +245,7 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     if ((rc = dalloc(h, &d.spx, (size_t)rppd::PMAX * h->n_inst))) return rc;
     if ((rc = dalloc(h, &d.spy, (size_t)rppd::PMAX * h->n_inst))) return rc;
     if ((rc = dalloc(h, &d.plans, (size_t)rppd::NUD * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.rawslot, tot))) return rc;
     d.curvature = p->curvature;
     d.goal_yaw_th = p->goal_yaw_th;
     d.goal_xy_th = p->goal_xy_th;
@@ -367,6 +368,7 @@ int rrtx_plan(rrtx_handle* h) {
   if (!h) return RRTX_E_INVALID;
   auto t0 = std::chrono::steady_clock::now();
   HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());   // uploads made through the null stream (obstacles, tables) are complete
   Ctx& c = h->c;
   const int B = h->n_inst;
   // f32-mirror margin = 2^-20 * the largest coordinate magnitude a node or sample is assumed to have (see scan2f);
@@ -492,9 +494,11 @@ int rrtx_plan(rrtx_handle* h) {
   }
   if (c.algo == RRTX_ALGO_INFORMED) {
     std::vector<double> inf(B, INFINITY);
-    HIPCHK(h, hipMemcpy(h->cbest, inf.data(), sizeof(double) * B, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpyAsync(h->cbest, inf.data(), sizeof(double) * B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));   // `inf` is a local
   }
-  if (is_dubins(c.algo)) HIPCHK(h, hipMemset(h->da.pool_used, 0, sizeof(int64_t) * B));
+  // on the handle's own stream: it is a non-blocking stream, work queued on the null stream is not ordered with it
+  if (is_dubins(c.algo)) HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
   rppi::InformedArgs ia;
   for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
   ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
@@ -909,7 +913,8 @@ int rrtx_smooth_planned(rrtx_handle* h, int32_t max_iter) {
   }
   std::vector<double> osz(rppk::MAX_OBS, 0.0);
   for (int k = 0; k < h->m; k++) osz[k] = h->obst[3 * k + 2];
-  HIPCHK(h, hipMemcpy(h->sm_osz, osz.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpyAsync(h->sm_osz, osz.data(), sizeof(double) * rppk::MAX_OBS, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // `osz` is a local; the kernel below is ordered after it anyway
   Ctx& c = h->c;
   rpps::SmoothArgs a{c.path_xy, c.path_cap, &c.inst[0].path_n, (int64_t)(sizeof(Inst) / sizeof(int32_t)),
                      &c.inst[0].rng, (int64_t)sizeof(Inst), c.ox, c.oy, h->sm_osz, h->m, max_iter,

@@ -295,6 +295,26 @@ def test_gpu_dubins_batch_equals_oracle(gpu):
             assert np.array_equal(out["paths"][i], r["path"])
 
 
+def _orc05(a):
+    import oracle
+    g, sd, it = a
+    r = oracle.plan_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], it, seed=sd)
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
+def test_gpu_dubins_many_seeds_equal_oracle(gpu):
+    """64 seeds x 3 000 iterations: long enough for the rare paths (e.g. a node rewired twice in one iteration because
+    equal-distance nodes collapse onto it in near_inds, rrt_05:1737-1738 -- 15 % of seeds hit that by 3 000 iterations)."""
+    from concurrent.futures import ProcessPoolExecutor
+    g = {k: v for k, v in util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it500.npz").items()}
+    seeds = list(range(330, 394))
+    out = util.run_gpu_dubins(g, seeds, max_iter=3000)
+    with ProcessPoolExecutor(max_workers=8) as ex:
+        refs = list(ex.map(_orc05, [(g, s, 3000) for s in seeds]))
+    for i, s in enumerate(seeds):
+        util.assert_tree_equal(out["trees"][i], refs[i], "seed %d" % s)
+
+
 def test_dubins_host_class_drop_in(gpu):
     import random
     import rrt_amd

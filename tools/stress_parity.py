@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Stress parity (GPU box): many seeds per planner, GPU trees vs the golden-pinned oracle, bit for bit.
+Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration)"""
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import util  # noqa: E402
+
+CNT = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+G05 = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it150.npz")
+G03 = util.load_golden(util.GOLDEN + "/rrt03_drv_s42_it200_sobol.npz")
+G07 = util.load_golden(sorted(util.golden_files("rrt07_c3"))[0])
+G07D = util.load_golden(sorted(util.golden_files("rrt07_drv"))[0])
+
+
+def o05(a):
+    import oracle
+    sd, it = a
+    r = oracle.plan_dubins(G05["start"], G05["goal"], G05["obstacles"], G05["rand_area"], it, seed=sd)
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
+def o03(a):
+    import oracle
+    sd, it, sob = a
+    r = oracle.plan_rrt_dubins(G03["start"], G03["goal"], G03["obstacles"], G03["rand_area"], it, seed=sd,
+                               robot_radius=float(G03["robot_radius"]), goal_sample_rate=10, sobol=bool(sob))
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
+def o04(a):
+    sd, kw = a
+    r = util.run_oracle(kw, sd, exact_pow=False)
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
+def o07(a):
+    import oracle
+    sd, kw = a
+    r = oracle.plan_informed(seed=sd, exact_pow=False, **kw)
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
+def compare(name, trees, refs):
+    bad = 0
+    for i, (t, r) in enumerate(zip(trees, refs)):
+        if not all(np.array_equal(a, b) for a, b in zip(t[:4], r)):
+            bad += 1
+            if bad <= 3:
+                print("   MISMATCH", name, "instance", i, "nodes", len(t[0]), len(r[0]))
+    print("%-40s %d instances: mismatches %d" % (name, len(trees), bad), flush=True)
+    return bad
+
+
+if __name__ == "__main__":
+    total = 0
+    with ProcessPoolExecutor(max_workers=14) as ex:
+        seeds = list(range(1, CNT + 1))
+        # rrt_05
+        g = dict(G05); g["max_iter"] = 4000
+        out = util.run_gpu_dubins(g, seeds)
+        total += compare("rrt_05 driver, 4000 it", out["trees"], list(ex.map(o05, [(s, 4000) for s in seeds])))
+        # rrt_03, both samplers
+        for sob in (1, 0):
+            g = dict(G03); g["max_iter"] = 3000; g["sobol"] = sob
+            out = util.run_gpu_rrt_dubins(g, seeds)
+            total += compare("rrt_03 driver, 3000 it, sobol=%d" % sob, out["trees"],
+                             list(ex.map(o03, [(s, 3000, sob) for s in seeds])))
+        # rrt_04: C2 map and driver map (play area, robot radius), MT and Sobol
+        for sob in (0, 1):
+            kw = util.c2_kwargs(4000); kw["sobol"] = sob
+            out = util.run_gpu_batch(kw, seeds)
+            total += compare("rrt_04 C2 map, 4000 it, sobol=%d" % sob, out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
+        kw = util.kwargs_from_golden(util.load_golden(util.GOLDEN + "/rrt04_drv_mt_s1234.npz")); kw["max_iter"] = 2000
+        out = util.run_gpu_batch(kw, seeds)
+        total += compare("rrt_04 driver map, 2000 it", out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
+        # rrt_07
+        for gg, it, nm in ((G07, 3000, "C3-style map"), (G07D, 2000, "driver map")):
+            kw7 = util.informed_kwargs_from_golden(gg)
+            kw7["max_iter"] = it
+            out = util.run_gpu_informed(kw7, seeds)
+            total += compare("rrt_07 %s, %d it" % (nm, it), out["trees"], list(ex.map(o07, [(s, kw7) for s in seeds])))
+    print("TOTAL mismatches", total)
+    sys.exit(1 if total else 0)
