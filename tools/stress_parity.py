@@ -46,6 +46,13 @@ def o07(a):
     return r["x"], r["y"], r["cost"], r["parent"]
 
 
+def o08(a):
+    import oracle
+    st, gl, obst, sd = a
+    r = oracle.plan_bitstar(st, gl, obst, [-2, 15], 80, seed=sd)
+    return r["g_scores"], r["path"]
+
+
 def compare(name, trees, refs):
     bad = 0
     for i, (t, r) in enumerate(zip(trees, refs)):
@@ -85,5 +92,44 @@ if __name__ == "__main__":
             kw7["max_iter"] = it
             out = util.run_gpu_informed(kw7, seeds)
             total += compare("rrt_07 %s, %d it" % (nm, it), out["trees"], list(ex.map(o07, [(s, kw7) for s in seeds])))
+        # rrt_01 (plain RRT, early exit) and rrt_04 early-exit mode on the driver map
+        kw1 = util.kwargs_from_golden(util.load_golden(sorted(util.golden_files("rrt01_drv"))[0]))
+        out = util.run_gpu_batch(kw1, seeds)
+        total += compare("rrt_01 driver", out["trees"], list(ex.map(o04, [(s, kw1) for s in seeds])))
+        kwe = util.kwargs_from_golden(util.load_golden(util.GOLDEN + "/rrt04_drv_mt_s1234.npz"))
+        kwe["search_until_max_iter"] = False
+        kwe["max_iter"] = 1500
+        out = util.run_gpu_batch(kwe, seeds)
+        total += compare("rrt_04 driver map, early exit", out["trees"], list(ex.map(o04, [(s, kwe) for s in seeds])))
+        # rrt_04 deeper trees, fewer seeds
+        kwd = util.c2_kwargs(20000)
+        sd2 = seeds[:48]
+        out = util.run_gpu_batch(kwd, sd2)
+        total += compare("rrt_04 C2 map, 20000 it", out["trees"], list(ex.map(o04, [(s, kwd) for s in sd2])))
+        # rrt_08 BIT*, C4-style instances
+        import random
+        obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+
+        def free_point(rng):
+            while True:
+                px, py = rng.uniform(-1, 14), rng.uniform(-1, 14)
+                if all((px - ox) ** 2 + (py - oy) ** 2 > r ** 2 for ox, oy, r in obst):
+                    return [px, py]
+        nb = 4 * CNT
+        starts, goals, bs = [], [], []
+        for i in range(nb):
+            rng = random.Random(2000 + i)
+            starts.append(free_point(rng)); goals.append(free_point(rng)); bs.append(1000 + i)
+        outb = util.run_gpu_bitstar(obst, [-2.0, 15.0], 80, bs, starts, goals)
+        refs = list(ex.map(o08, [(starts[i], goals[i], obst, bs[i]) for i in range(nb)]))
+        bad = 0
+        for i in range(nb):
+            x, y, cost, parent = outb["trees"][i]
+            r = refs[i]
+            p = outb["paths"][i]
+            ok = np.array_equal(cost, r[0]) and ((p is None and len(r[1]) == 0) or np.array_equal(p, r[1])) and len(x) == len(r[0])
+            bad += 0 if ok else 1
+        print("%-40s %d instances: mismatches %d" % ("rrt_08 C4-style, 80 it", nb, bad), flush=True)
+        total += bad
     print("TOTAL mismatches", total)
     sys.exit(1 if total else 0)
