@@ -131,5 +131,31 @@ if __name__ == "__main__":
             bad += 0 if ok else 1
         print("%-40s %d instances: mismatches %d" % ("rrt_08 C4-style, 80 it", nb, bad), flush=True)
         total += bad
+        # path smoothing: random polylines through two obstacles, own MT19937 streams
+        import rrt_amd
+        import oracle as orc
+        paths, states, exp, exp_pos = [], [], [], []
+        sobst = [(8.0, -2.0, 1.0), (20.0, 9.0, 1.5), (30.0, 4.0, 1.0)]
+        for i in range(CNT):
+            rng = random.Random(7000 + i)
+            pts = [[0.0, 0.0]]
+            for k in range(20 + (i % 120)):
+                pts.append([pts[-1][0] + rng.uniform(0.2, 1.0), pts[-1][1] + rng.uniform(-0.8, 1.0)])
+            paths.append(np.array(pts[::-1]))
+            mt = orc.mt_from_seed(9000 + i)
+            states.append((np.array([mt.mt[j] for j in range(624)], dtype=np.uint32), int(mt.pos)))
+            try:
+                exp.append(orc.path_smoothing(paths[-1], 500, sobst, mt))
+            except RuntimeError:
+                exp.append(None)   # the reference raises ZeroDivisionError on this input
+            exp_pos.append((int(mt.pos), int(mt.mt[0])))
+        keep = [i for i in range(CNT) if exp[i] is not None]
+        outp, st2, _ = rrt_amd._abi.smooth_paths([paths[i] for i in keep], 500, sobst, [states[i] for i in keep])
+        bad = 0
+        for j, i in enumerate(keep):
+            ok = np.array_equal(outp[j], exp[i]) and st2[j][1] == exp_pos[i][0] and int(st2[j][0][0]) == exp_pos[i][1]
+            bad += 0 if ok else 1
+        print("%-40s %d instances: mismatches %d" % ("path_smoothing, 500 it", len(keep), bad), flush=True)
+        total += bad
     print("TOTAL mismatches", total)
     sys.exit(1 if total else 0)
