@@ -48,7 +48,9 @@ enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
        RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
 
 /* per-instance status bits (rrtx_get_results) */
-enum { RRTX_ST_DONE = 1, RRTX_ST_PATH = 2, RRTX_ST_OVERFLOW = 4, RRTX_ST_PATH_TRUNC = 8 };
+enum { RRTX_ST_DONE = 1, RRTX_ST_PATH = 2, RRTX_ST_OVERFLOW = 4, RRTX_ST_PATH_TRUNC = 8,
+       RRTX_ST_UNSUPPORTED = 16 /* a reference code path the device kernel does not restate was reached (see
+                                   rrtx_last_error); the instance stops there instead of continuing differently */ };
 
 /* Constructor arguments of the reference classes (rrt_04:951-1000, rrt_01:32-69). */
 typedef struct rrtx_params {

@@ -1119,6 +1119,9 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
               x[u] = sh.edge[0].ex;
               y[u] = sh.edge[0].ey;
               sh.nvalid = 1;
+              // the moved node listed again in near_inds (distance tie, :1337) would be re-steered by the
+              // reference's second visit: not restated here -> stop loudly (RRTX_ST_UNSUPPORTED), see v2 body
+              if (nvalid > nu) sh.overflow = 2;
             }
             cost[u] = sh.uval[es];
             link_child(parent, first_child, next_sib, prev_sib, u, newidx);
@@ -1223,7 +1226,8 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
     I->n = n;
     I->it = it;
     if (done) I->status |= 1;
-    if (sh.overflow) I->status |= 4;
+    if (sh.overflow == 1) I->status |= 4;
+    if (sh.overflow == 2) I->status |= 16;
     I->iterations += s_iter;
     I->edges_unique += s_eu;
     I->edges_ref += s_er;

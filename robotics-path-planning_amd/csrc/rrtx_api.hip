@@ -539,7 +539,7 @@ int rrtx_plan(rrtx_handle* h) {
   rrtx_stats& s = h->stats;
   memset(&s, 0, sizeof(s));
   memset(h->phase, 0, sizeof(h->phase));
-  bool overflow = false;
+  bool overflow = false, unsupported = false;
   for (int i = 0; i < B; i++) {
     const Inst& I = back[i];
     s.iterations += I.iterations;
@@ -558,6 +558,7 @@ int rrtx_plan(rrtx_handle* h) {
     s.q16_fallbacks += I.q16_fallbacks;
     if (I.nu_max > s.near_unique_max) s.near_unique_max = I.nu_max;
     if (I.status & RRTX_ST_OVERFLOW) overflow = true;
+    if (I.status & RRTX_ST_UNSUPPORTED) unsupported = true;
     for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];
   }
   s.launches = launches;
@@ -567,6 +568,11 @@ int rrtx_plan(rrtx_handle* h) {
   if (overflow) {
     h->err = "a fixed on-device capacity was exceeded (near-candidate list NU_MAX, polyline pool, or a BIT* slab)";
     return RRTX_E_OVERFLOW;
+  }
+  if (unsupported) {
+    h->err = "rrt_04 rewire: a node moved by an unsnapped steer is listed again in near_inds (distance tie); the "
+             "reference's second visit is not restated on the device";
+    return RRTX_E_STATE;
   }
   return RRTX_OK;
 }
