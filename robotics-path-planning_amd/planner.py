@@ -577,5 +577,26 @@ class BatchPlanner:
     def path(self, i):
         return self.h.get_path(i)
 
+    def smooth(self, max_iter):
+        """path_smoothing(path, max_iter, obstacle_list) (rrt_04:1447-1479) on every planned path, on the device, each
+        instance continuing its own random stream (as the driver does at :1558-1559)."""
+        self.h.smooth_planned(max_iter)
+        return [self.h.get_smoothed_path(i) for i in range(len(self.seeds))]
+
+    def export_npz(self, filename, instances=None):
+        """Compact on-disk form of the planned trees for plotting / regression diffs: per instance
+        (x, y, cost, parent) as the reference's node_list holds them, the returned path, path cost, seed."""
+        ids = list(range(len(self.seeds))) if instances is None else list(instances)
+        pc, nn, st = self.h.get_results()
+        out = dict(seeds=np.array([self.seeds[i] for i in ids], dtype=np.int64), path_cost=pc[ids], n_nodes=nn[ids],
+                   status=st[ids])
+        for k, i in enumerate(ids):
+            x, y, cost, parent = self.h.get_tree(i)
+            p = self.h.get_path(i)
+            out["x_%d" % k], out["y_%d" % k], out["cost_%d" % k], out["parent_%d" % k] = x, y, cost, parent
+            out["path_%d" % k] = np.zeros((0, 2)) if p is None else p
+        np.savez_compressed(filename, **out)
+        return filename
+
     def close(self):
         self.h.close()

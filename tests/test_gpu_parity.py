@@ -548,3 +548,22 @@ def test_driver_sequence_planning_then_smoothing(gpu):
             assert st[1][624] == int(gold[sd]["rng_pos_after"]) and st[1][0] == int(gold[sd]["rng_word0_after"])
     finally:
         h.close()
+
+
+def test_batch_planner_smooth_and_export(gpu, tmp_path):
+    """BatchPlanner: device-resident smoothing of every planned path and the NPZ tree export."""
+    import rrt_amd
+    obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)]
+    bp = rrt_amd.BatchPlanner("rrt_star", [1234, 5, 7], [0, 0], [6.0, 10.0], obst, [-2, 15], expand_dis=1.0,
+                              path_resolution=0.1, goal_sample_rate=5, max_iter=500, play_area=[0, 10, 0, 14],
+                              robot_radius=0.6, connect_circle_dist=50.0, search_until_max_iter=True)
+    try:
+        bp.plan()
+        f = bp.export_npz(str(tmp_path / "trees.npz"))
+        z = np.load(f)
+        g = util.load_golden(util.GOLDEN + "/smooth_drv_s1234.npz")
+        assert np.array_equal(z["path_0"], g["path_in"]) and len(z["x_0"]) == int(z["n_nodes"][0])
+        sm = bp.smooth(1000)
+        assert np.array_equal(sm[0], g["smoothed"])
+    finally:
+        bp.close()
