@@ -200,8 +200,13 @@ def main():
                 traffic_note = "HBM bytes/step %.4g from profiles/%s" % (tj["hbm_bytes_per_step"], tf)
                 break
         line = {
-            "metric": "%s collision-checked edge expansions/sec (unique edges evaluated on device), "
-                      "%d-iteration trees" % ("RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"), a.max_iter),
+            # BASELINE.json: "RRT* edge expansions/sec + final path cost, 100k-node tree"; the path cost is reported in
+            # final_path_cost_mean / _min below
+            "metric": "%s edge expansions/sec + final path cost, %s tree (collision-checked edges evaluated on the "
+                      "device, distinct per iteration; %d iterations)"
+                      % ("RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"),
+                         "100k-node" if (not c3 and not c5 and a.max_iter >= 100000) else "%d-iteration" % a.max_iter,
+                         a.max_iter),
             "value": value, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": steps_done, "warmup": a.warmup,
             "ms_per_step": 1e3 * tmax / max(steps_done, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
