@@ -504,6 +504,56 @@ def main_smooth(only=""):
         smooth_and_store(name, pts[::-1], 600, obst)
 
 
+def main06_kat(only=""):
+    """Reeds-Shepp primitive known-answer vectors: reeds_shepp_path_planning (rrt_06:1426-1441) on random pose pairs,
+    the driver's curvature / step (rrt_06: curvature 1.0, step_size 0.2) and two others.  Groundwork for rrt_06
+    (SURVEY 8f rank 2): pins the oracle's restatement of the solver before a planner is built on it."""
+    m06 = ref_loader.load("rrt_06")
+    rng = random.Random(6)
+    rows = []
+    for k in range(600):
+        sx, sy, syaw = rng.uniform(-2, 15), rng.uniform(-2, 15), rng.uniform(-math_pi(), math_pi())
+        gx, gy, gyaw = rng.uniform(-2, 15), rng.uniform(-2, 15), rng.uniform(-math_pi(), math_pi())
+        if k % 7 == 0:
+            gx, gy = sx + rng.uniform(-0.6, 0.6), sy + rng.uniform(-0.6, 0.6)
+        if k % 11 == 0:
+            gyaw = syaw
+        if k % 13 == 0:
+            syaw = [0.0, math_pi() / 2, -math_pi() / 2, math_pi() / 4][k % 4]
+            gyaw = syaw if k % 2 else -syaw
+            gx, gy = sx + (1 + k % 5), sy
+        maxc = [1.0, 1.0, 0.5, 2.0][k % 4]
+        step = [0.2, 0.2, 0.2, 0.1][k % 4]
+        err = ""
+        with contextlib.redirect_stdout(io.StringIO()):
+            try:
+                px, py, pyaw, mode, lengths = m06.reeds_shepp_path_planning(sx, sy, syaw, gx, gy, gyaw, maxc, step)
+            except (ZeroDivisionError, ValueError) as e:   # the reference raises on degenerate poses (u1 == 0, |arg| > 1)
+                err = type(e).__name__
+                px = None
+        if err:
+            rows.append(dict(inp=[sx, sy, syaw, gx, gy, gyaw, maxc, step], n=-1, mode=err, lengths=[], px=np.zeros(0),
+                             py=np.zeros(0), pyaw=np.zeros(0)))
+        elif px is None:
+            rows.append(dict(inp=[sx, sy, syaw, gx, gy, gyaw, maxc, step], n=0, mode="", lengths=[], px=np.zeros(0),
+                             py=np.zeros(0), pyaw=np.zeros(0)))
+        else:
+            rows.append(dict(inp=[sx, sy, syaw, gx, gy, gyaw, maxc, step], n=len(px), mode="".join(mode),
+                             lengths=[float(v) for v in lengths], px=np.asarray(px, dtype=np.float64),
+                             py=np.asarray(py, dtype=np.float64), pyaw=np.asarray(pyaw, dtype=np.float64)))
+    ml = max(len(r["lengths"]) for r in rows)
+    np.savez_compressed(os.path.join(OUT, "rs_kat.npz"),
+                        inp=np.array([r["inp"] for r in rows]), n=np.array([r["n"] for r in rows], dtype=np.int32),
+                        mode=np.array([r["mode"] for r in rows]),
+                        n_len=np.array([len(r["lengths"]) for r in rows], dtype=np.int32),
+                        lengths=np.array([r["lengths"] + [0.0] * (ml - len(r["lengths"])) for r in rows]),
+                        poly_x=np.concatenate([r["px"] for r in rows]), poly_y=np.concatenate([r["py"] for r in rows]),
+                        poly_yaw=np.concatenate([r["pyaw"] for r in rows]))
+    print("rs_kat: %d cases, %d with a path, %d raise, modes %s" % (len(rows), sum(1 for r in rows if r["n"] > 0),
+                                                          sum(1 for r in rows if r["n"] < 0),
+                                                          sorted({r["mode"] for r in rows})[:8]), flush=True)
+
+
 def math_pi():
     import math
     return math.pi

@@ -349,3 +349,28 @@ def path_smoothing(path, max_iter, obstacles, rng):
     if rc != 0:
         raise RuntimeError("orc_path_smoothing failed: %d" % rc)
     return out[:n.value].copy()
+
+
+def reeds_shepp(sx, sy, syaw, gx, gy, gyaw, maxc, step_size=0.2):
+    """reeds_shepp_path_planning (rrt_06:1426-1441) on the oracle -> (px, py, pyaw, mode, lengths), all None where the
+    reference returns None; raises ZeroDivisionError / ValueError where the reference does."""
+    L = lib()
+    L.orc_reeds_shepp.restype = C.c_int
+    L.orc_reeds_shepp.argtypes = [C.c_double] * 8 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_char_p,
+                                                     C.c_void_p]
+    cap = 8192
+    px = np.zeros(cap); py = np.zeros(cap); pyaw = np.zeros(cap); ln = np.zeros(5)
+    mode = C.create_string_buffer(8)
+    nl = C.c_int(0)
+    n = L.orc_reeds_shepp(float(sx), float(sy), float(syaw), float(gx), float(gy), float(gyaw), float(maxc),
+                          float(step_size), px.ctypes.data, py.ctypes.data, pyaw.ctypes.data, cap, ln.ctypes.data, mode,
+                          C.byref(nl))
+    if n == -3:
+        raise ZeroDivisionError("float division by zero")
+    if n == -4:
+        raise ValueError("math domain error")
+    if n < 0:
+        raise RuntimeError("orc_reeds_shepp: capacity")
+    if n == 0:
+        return None, None, None, None, None
+    return px[:n].copy(), py[:n].copy(), pyaw[:n].copy(), mode.value.decode(), ln[:nl.value].copy()

@@ -23,6 +23,7 @@ FILES = {
     "rrt_03": "10_path_planning_01_rrt_03_dubins_path.py",
     "rrt_04": "10_path_planning_01_rrt_04_rrt_star.py",
     "rrt_05": "10_path_planning_01_rrt_05_rrt_star_dubins_path.py",
+    "rrt_06": "10_path_planning_01_rrt_06_rrt_star_reeds_shepp_path.py",
     "rrt_07": "10_path_planning_01_rrt_07_informed_rrt_star.py",
     "rrt_08": "10_path_planning_01_rrt_08_batch_informed_rrt_star.py",
 }

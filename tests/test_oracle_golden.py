@@ -175,3 +175,29 @@ def test_path_smoothing_oracle_matches_reference_golden(path):
     sm = oracle.path_smoothing(g["path_in"], int(g["max_iter"]), g["obstacles"], rng)
     assert np.array_equal(sm, g["smoothed"])
     assert rng.pos == int(g["rng_pos_after"]) and rng.mt[0] == int(g["rng_word0_after"])
+
+
+def test_reeds_shepp_oracle_matches_reference_kat():
+    """Groundwork for rrt_06: the oracle's Reeds-Shepp solver against 600 known-answer vectors of the
+    reference's reeds_shepp_path_planning (word, segment lengths, every path point and yaw; None and raising cases)."""
+    import oracle
+    g = np.load(util.GOLDEN + "/rs_kat.npz")
+    off = 0
+    for k in range(len(g["inp"])):
+        a = [float(v) for v in g["inp"][k]]
+        n = int(g["n"][k])
+        if n < 0:
+            with pytest.raises((ZeroDivisionError, ValueError)) as ei:
+                oracle.reeds_shepp(*a)
+            assert ei.type.__name__ == str(g["mode"][k]), k
+            continue
+        px, py, pyaw, mode, ln = oracle.reeds_shepp(*a)
+        if n == 0:
+            assert px is None, k
+            continue
+        assert px is not None and len(px) == n, (k, n, None if px is None else len(px))
+        assert mode == str(g["mode"][k]), k
+        assert np.array_equal(ln, g["lengths"][k][:int(g["n_len"][k])]), k
+        assert np.array_equal(px, g["poly_x"][off:off + n]) and np.array_equal(py, g["poly_y"][off:off + n]), k
+        assert np.array_equal(pyaw, g["poly_yaw"][off:off + n]), k
+        off += n
