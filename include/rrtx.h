@@ -180,6 +180,9 @@ int rrtx_smooth_paths(int32_t device, int32_t n_jobs, const double* paths_xy, co
 int rrtx_smooth_planned(rrtx_handle* h, int32_t max_iter);
 int rrtx_get_smoothed_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_points, int32_t* n_out);
 
+/* parity harness: out[i] = op(a[i], b[i]) evaluated on the device.  op 0 math.hypot, 1 x**2, 2 sin, 3 cos, 4 atan2,
+ * 5 steer end x (rrt_04:1086-1115), 6 sqrt, 7 a/b, 8 acos, 9 asin, 10 checksum of the Reeds-Shepp steer
+ * (0,0,0) -> (a, b, a+b) (rrt_06:1426-1441, csrc/rpp_rs.h) */
 int rrtx_selftest_math(int32_t device, int32_t op, const double* a, const double* b, double* out, int64_t n);
 
 #ifdef __cplusplus

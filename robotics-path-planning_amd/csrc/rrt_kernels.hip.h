@@ -31,6 +31,7 @@
 #include <stdint.h>
 
 #include "rpp_core.h"
+#include "rpp_rs.h"
 
 namespace rppk {
 
@@ -1313,6 +1314,14 @@ __global__ void selftest_kernel(int op, const double* a, const double* b, double
     } break;
     case 6: r = __builtin_sqrt(a[i]); break;
     case 7: r = a[i] / b[i]; break;
+    case 8: r = rpp_glibc_acos(a[i]); break;
+    case 9: r = rpp_glibc_asin(a[i]); break;
+    case 10: {   // Reeds-Shepp steer (rpp_rs.h): (0, 0, 0) -> (a, b, a + b), curvature 1, step 0.2: checksum of the path
+      double px[256], py[256], pyaw[256];
+      rpp::RsResult R;
+      rpp::rs_plan(0.0, 0.0, 0.0, a[i], b[i], a[i] + b[i], 1.0, 0.2, px, py, pyaw, 256, &R);
+      r = (R.err || R.n == 0 || R.n > 256) ? (double)R.err - 1000.0 * R.n : px[R.n - 1] + py[R.n / 2] + pyaw[R.n - 1] + R.len[0];
+    } break;
   }
   o[i] = r;
 }

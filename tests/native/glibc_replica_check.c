@@ -10,8 +10,8 @@ static inline uint64_t rnd(){ s^=s<<13; s^=s>>7; s^=s<<17; return s; }
 static inline double u01(){ return (rnd()>>11)*(1.0/9007199254740992.0); }
 int main(int argc,char**argv){
   long N = argc>1? atol(argv[1]):10000000;
-  long bad[5]={0,0,0,0,0}; int o;
-  double (*volatile pacos)(double)=acos;
+  long bad[6]={0,0,0,0,0,0}; int o;
+  double (*volatile pacos)(double)=acos; double (*volatile pasin)(double)=asin;
   double (*volatile psin)(double)=sin; double (*volatile pcos)(double)=cos;
   double (*volatile patan2)(double,double)=atan2; double (*volatile ppow)(double,double)=pow;
   for(long i=0;i<N;i++){
@@ -31,7 +31,9 @@ int main(int argc,char**argv){
     double ac=(u01()*2-1); if(i%17==0) ac*=1e-4; if(i%19==0) ac = ac>0? 1-ac*1e-6 : -1-ac*1e-6; if(i%997==1) ac=1; if(i%997==2) ac=-1;
     a=rpp_glibc_acos(ac); b=pacos(ac);
     if(memcmp(&a,&b,8)){ if(bad[4]++<5) printf("acos %a: %a vs %a\n",ac,a,b);}
+    a=rpp_glibc_asin(ac); b=pasin(ac);
+    if(memcmp(&a,&b,8)){ if(bad[5]++<5) printf("asin %a: %a vs %a\n",ac,a,b);}
   }
-  printf("N=%ld mismatches sin=%ld cos=%ld atan2=%ld pow=%ld acos=%ld\n",N,bad[0],bad[1],bad[2],bad[3],bad[4]);
-  return (bad[0]||bad[1]||bad[2]||bad[3]||bad[4]);
+  printf("N=%ld mismatches sin=%ld cos=%ld atan2=%ld pow=%ld acos=%ld asin=%ld\n",N,bad[0],bad[1],bad[2],bad[3],bad[4],bad[5]);
+  return (bad[0]||bad[1]||bad[2]||bad[3]||bad[4]||bad[5]);
 }

@@ -119,3 +119,29 @@ def test_bitstar_core_against_goldens_and_oracle(builddir):
         assert r["error"] == o["error"]
         assert np.array_equal(r["vertex_ids"], o["vertex_ids"]) and np.array_equal(r["g_scores"], o["g_scores"])
         assert np.array_equal(r["path"], o["path"]) and np.array_equal(r["tr_e0"], o["tr_e0"])
+
+
+def test_reeds_shepp_core_against_reference_kat(builddir):
+    """rpp_rs.h (host + device source of the Reeds-Shepp steer, groundwork for rrt_06) against the reference's 600
+    known-answer vectors: word, lengths, every point and yaw, None and raising cases -- bit for bit."""
+    import struct
+    import numpy as np
+    g = np.load(os.path.join(util.GOLDEN, "rs_kat.npz"))
+    blob = os.path.join(builddir, "rs_kat.bin")
+    off = 0
+    with open(blob, "wb") as f:
+        for k in range(len(g["inp"])):
+            n = int(g["n"][k])
+            f.write(np.asarray(g["inp"][k], dtype=np.float64).tobytes())
+            f.write(struct.pack("<ii", n, int(g["n_len"][k])))
+            f.write(str(g["mode"][k]).encode()[:7].ljust(8, b"\0"))
+            f.write(np.asarray(g["lengths"][k][:5], dtype=np.float64).tobytes())
+            if n > 0:
+                for key in ("poly_x", "poly_y", "poly_yaw"):
+                    f.write(np.asarray(g[key][off:off + n], dtype=np.float64).tobytes())
+                off += n
+    exe = os.path.join(builddir, "rs_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-I", CSRC,
+                    os.path.join(util.ROOT, "tests", "native", "rs_host_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, blob], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

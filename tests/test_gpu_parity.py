@@ -40,6 +40,27 @@ def test_device_arithmetic_replicas(gpu):
     bb = np.where(b == 0, 1.0, b)
     got = sel(7, a, bb)
     assert np.array_equal(got, a / bb), "division"
+    u = rng.random(n) * 2 - 1
+    u[::17] *= 1e-4
+    u[::19] = np.sign(u[::19]) * (1 - np.abs(u[::19]) * 1e-6)
+    got = sel(8, u, b)
+    assert all(got[i] == math.acos(u[i]) for i in range(n)), "acos"
+    got = sel(9, u, b)
+    assert all(got[i] == math.asin(u[i]) for i in range(n)), "asin"
+    # Reeds-Shepp steer core (rpp_rs.h, groundwork for rrt_06) on the device vs the oracle's restatement
+    m = 3000
+    gx = (rng.random(m) * 2 - 1) * 8
+    gy = (rng.random(m) * 2 - 1) * 8
+    got = sel(10, gx, gy)
+    for i in range(m):
+        try:
+            px, py, pyaw, mode, ln = oracle.reeds_shepp(0.0, 0.0, 0.0, gx[i], gy[i], gx[i] + gy[i], 1.0, 0.2)
+        except (ZeroDivisionError, ValueError):
+            continue
+        if px is None or len(px) > 256:
+            continue
+        k = len(px)
+        assert got[i] == px[k - 1] + py[k // 2] + pyaw[k - 1] + ln[0], ("reeds-shepp", i)
     # steer end point (constructed near-ties included): (0,0) -> (a,b) scaled to length ~2.0
     ang = th
     tx = 2.0 * np.cos(ang)

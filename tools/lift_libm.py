@@ -26,7 +26,7 @@ save/restore (MXCSR) is dropped: callers run in round-to-nearest.
 Branches that leave the restated domain (huge-argument reduction `__branred`,
 overflow/underflow error exits of pow) return NaN and raise the `ood` flag.
 
-Output: one header with `static inline double rpp_glibc_{sin,cos,atan2,pow,acos}`.
+Output: one header with `static inline double rpp_glibc_{sin,cos,atan2,pow,acos,asin}`.
 Verified against the live libm by tests/test_glibc_math.py.
 
 Usage: python tools/lift_libm.py [--libm PATH] [--out HEADER]
@@ -41,6 +41,7 @@ import sys
 FUNCS = [
     # name, entry, end(exclusive), args
     ("pow", 0x768b0, 0x76ee0, 2),
+    ("asin", 0x772b0, 0x77960, 1),
     ("acos", 0x77960, 0x78060, 1),
     ("atan2", 0x78060, 0x789b0, 2),
     ("sin", 0x789b0, 0x791c0, 1),
@@ -760,6 +761,7 @@ RPP_HD static inline double rpp_glibc_cos(double x) { int o = 0; return rpp_glib
 RPP_HD static inline double rpp_glibc_atan2(double y, double x) { int o = 0; return rpp_glibc_atan2_raw(y, x, &o); }
 RPP_HD static inline double rpp_glibc_pow(double x, double y) { int o = 0; return rpp_glibc_pow_raw(x, y, &o); }
 RPP_HD static inline double rpp_glibc_acos(double x) { int o = 0; return rpp_glibc_acos_raw(x, &o); }
+RPP_HD static inline double rpp_glibc_asin(double x) { int o = 0; return rpp_glibc_asin_raw(x, &o); }
 """)
     print("wrote", a.out)
     return 0
