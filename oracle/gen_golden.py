@@ -504,6 +504,70 @@ def main_smooth(only=""):
         smooth_and_store(name, pts[::-1], 600, obst)
 
 
+def run_rrt06(mod, name, obstacles, start, goal, rand_area, max_iter, seed, curvature=2.0, robot_radius=0.6,
+              expand_dis=3.0, ccd=50.0, step_size=0.1, until_max=True):
+    """RRT*-Reeds-Shepp (rrt_06:1444-1914), driver-style call planning(animation=False) (:2087: search_until_max_iter
+    is planning()'s own default True; the constructor's flag is not read)."""
+    random.seed(seed)
+    rrt = mod.RRT(start=start, goal=goal, obstacle_list=obstacles, rand_area=rand_area, expand_dis=expand_dis,
+                  path_resolution=0.5, goal_sample_rate=10, max_iter=max_iter, play_area=None,
+                  robot_radius=robot_radius, sobol_sampler=True, connect_circle_dist=ccd, search_until_max_iter=False,
+                  curvature=curvature, goal_yaw_th=np.deg2rad(1.0), goal_xy_th=0.5, step_size=step_size)
+    tr = {"rx": [], "ry": [], "ryaw": [], "nearest": [], "n_near": []}
+    o_near = mod.RRT.get_nearest_node_index
+    o_fn = rrt.find_near_nodes
+
+    def near_hook(node_list, rnd):
+        i = o_near(node_list, rnd)
+        tr["rx"].append(float(rnd.x)); tr["ry"].append(float(rnd.y)); tr["ryaw"].append(float(rnd.yaw))
+        tr["nearest"].append(i)
+        return i
+
+    def fn_hook(new_node):
+        r = o_fn(new_node)
+        tr["n_near"].append(len(r))
+        return r
+    rrt.get_nearest_node_index = near_hook
+    rrt.find_near_nodes = fn_hook
+    t0 = time.time()
+    with contextlib.redirect_stdout(io.StringIO()):
+        path = rrt.planning(animation=False) if until_max else rrt.planning(animation=False, search_until_max_iter=False)
+    dt = time.time() - t0
+    nl = rrt.node_list
+    x, y, cost, parent = tree_arrays(nl)
+    yaw = np.array([float(nd.yaw) for nd in nl])
+    plen = np.array([len(nd.path_x) for nd in nl], dtype=np.int32)
+    ppx = np.concatenate([np.asarray(nd.path_x, dtype=np.float64).reshape(-1) for nd in nl])
+    ppy = np.concatenate([np.asarray(nd.path_y, dtype=np.float64).reshape(-1) for nd in nl])
+    state = random.getstate()
+    out = dict(algo="rrt_star_reeds_shepp", seed=seed, search_until_max_iter=int(bool(until_max)),
+               obstacles=np.array(obstacles, dtype=np.float64), start=np.array(start, dtype=np.float64),
+               goal=np.array(goal, dtype=np.float64), rand_area=np.array(rand_area, dtype=np.float64), max_iter=max_iter,
+               curvature=curvature, robot_radius=robot_radius, expand_dis=expand_dis, connect_circle_dist=ccd,
+               step_size=step_size, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5,
+               x=x, y=y, yaw=yaw, cost=cost, parent=parent, poly_len=plen, poly_x=ppx, poly_y=ppy,
+               path=np.array(path if path is not None else [], dtype=np.float64).reshape(-1, 3),
+               path_found=int(path is not None), ref_seconds=dt,
+               rng_pos_after=state[1][624], rng_word0_after=np.uint32(state[1][0]),
+               tr_rx=np.array(tr["rx"]), tr_ry=np.array(tr["ry"]), tr_ryaw=np.array(tr["ryaw"]),
+               tr_nearest=np.array(tr["nearest"], dtype=np.int32), tr_n_near=np.array(tr["n_near"], dtype=np.int32))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%-28s nodes=%d path=%s maxcost=%r  %.2fs" % (name, len(x), None if path is None else len(path),
+                                                        float(cost.max()), dt), flush=True)
+
+
+def main06(only=""):
+    """rrt_06 driver scene (:2012-2083): curvature 2.0, step_size 0.1, robot_radius 0.6, goal (10, 9, 0)."""
+    m06 = ref_loader.load("rrt_06")
+    obst = [(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)]      # rrt_06:2012-2014
+    drv = dict(obstacles=obst, start=[0.0, 0.0, float(np.deg2rad(0.0))], goal=[10.0, 9.0, float(np.deg2rad(0.0))],
+               rand_area=[-2, 15])
+    for seed, it, um in ((42, 200, True), (1, 300, True), (7, 750, True), (3, 400, False), (11, 400, False)):
+        n = "rrt06_drv_s%d_it%d%s" % (seed, it, "" if um else "_early")
+        if n.startswith(only):
+            run_rrt06(m06, n, max_iter=it, seed=seed, until_max=um, **drv)
+
+
 def main06_kat(only=""):
     """Reeds-Shepp primitive known-answer vectors: reeds_shepp_path_planning (rrt_06:1426-1441) on random pose pairs,
     the driver's curvature / step (rrt_06: curvature 1.0, step_size 0.2) and two others.  Groundwork for rrt_06

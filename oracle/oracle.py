@@ -37,7 +37,7 @@ class Out(C.Structure):
                 ("cap", C.c_int32), ("n", C.c_int32),
                 ("path_xy", C.c_void_p), ("path_cap", C.c_int32), ("path_n", C.c_int32),
                 ("tr_rnd_x", C.c_void_p), ("tr_rnd_y", C.c_void_p), ("tr_nearest", C.c_void_p),
-                ("tr_n_near", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32)]
+                ("tr_n_near", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32), ("path_yaw", C.c_void_p)]
 
 
 def build():
@@ -189,7 +189,7 @@ class DOut(C.Structure):
                 ("poly_cap", C.c_int64), ("poly_n", C.c_int64),
                 ("path_xy", C.c_void_p), ("path_cap", C.c_int32), ("path_n", C.c_int32),
                 ("tr_rx", C.c_void_p), ("tr_ry", C.c_void_p), ("tr_ryaw", C.c_void_p), ("tr_nearest", C.c_void_p),
-                ("tr_n_near", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32)]
+                ("tr_n_near", C.c_void_p), ("tr_cap", C.c_int32), ("tr_n", C.c_int32), ("path_yaw", C.c_void_p)]
 
 
 def dubins(sx, sy, syaw, gx, gy, gyaw, curvature=1.0, cap=4096):
@@ -214,11 +214,25 @@ def plan_rrt_dubins(start, goal, obstacles, rand_area, max_iter=200, seed=None, 
                        _sobol=sobol, _play_area=play_area)
 
 
+def plan_rrt_rs(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=None, curvature=1.0, robot_radius=0.0,
+                expand_dis=3.0, connect_circle_dist=50.0, goal_yaw_th=None, goal_xy_th=0.5, step_size=0.2, trace=False,
+                search_until_max_iter=True):
+    """One RRT.planning(animation=False) call of rrt_06 (RRT*-Reeds-Shepp, :1530-1570) on the oracle.  The returned
+    dict's `path` / `path_yaw` are the three columns of generate_final_course (:1643-1651)."""
+    return plan_dubins(start, goal, obstacles, rand_area, max_iter, seed=seed, rng=rng, curvature=curvature,
+                       robot_radius=robot_radius, expand_dis=expand_dis, connect_circle_dist=connect_circle_dist,
+                       goal_yaw_th=goal_yaw_th, goal_xy_th=goal_xy_th, trace=trace,
+                       search_until_max_iter=search_until_max_iter, _rs_step=float(step_size))
+
+
 def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=None, curvature=1.0, robot_radius=0.0,
                 goal_sample_rate=10, expand_dis=3.0, connect_circle_dist=50.0, goal_yaw_th=None, goal_xy_th=0.5,
-                trace=False, search_until_max_iter=True, _plain=False, _sobol=False, _play_area=None):
+                trace=False, search_until_max_iter=True, _plain=False, _sobol=False, _play_area=None, _rs_step=0.0):
     """One RRT.planning(animation=False) call of rrt_05 (RRT*-Dubins) on the oracle."""
     L = lib()
+    L.orc_plan_rrt_rs.restype = C.c_int
+    L.orc_plan_rrt_rs.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_plan_dubins.restype = C.c_int
     L.orc_plan_dubins.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p,
                                   C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -244,12 +258,13 @@ def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=
     obst = np.ascontiguousarray(np.array(obstacles, dtype=np.float64).reshape(-1, 3))
     if rng is None:
         rng = mt_from_seed(seed)
-    cap = int(max_iter) + 2
+    cap = (2 if _rs_step > 0 else 1) * int(max_iter) + 2
     pcap = cap * 2048
     x = np.zeros(cap); y = np.zeros(cap); yaw = np.zeros(cap); cost = np.zeros(cap); parent = np.zeros(cap, dtype=np.int32)
     plen = np.zeros(cap, dtype=np.int32); ppx = np.zeros(pcap); ppy = np.zeros(pcap)
-    path = np.zeros((pcap, 2))
+    path = np.zeros((pcap, 2)); path_yaw = np.zeros(pcap)
     o = DOut()
+    o.path_yaw = path_yaw.ctypes.data
     o.x, o.y, o.yaw, o.cost, o.parent = x.ctypes.data, y.ctypes.data, yaw.ctypes.data, cost.ctypes.data, parent.ctypes.data
     o.cap = cap
     o.poly_len, o.poly_x, o.poly_y, o.poly_cap = plen.ctypes.data, ppx.ctypes.data, ppy.ctypes.data, pcap
@@ -262,7 +277,11 @@ def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=
         o.tr_cap = int(max_iter)
     st = Stats()
     sob_idx = C.c_int64(0)
-    if _plain:
+    if _rs_step > 0:
+        rc = L.orc_plan_rrt_rs(C.byref(p), float(start[2]), float(goal[2]), float(curvature), float(goal_yaw_th),
+                               float(goal_xy_th), float(_rs_step), obst.ctypes.data, len(obst), C.byref(rng), C.byref(o),
+                               C.byref(st))
+    elif _plain:
         rc = L.orc_plan_rrt_dubins(C.byref(p), float(start[2]), float(goal[2]), float(curvature), float(goal_yaw_th),
                                    float(goal_xy_th), obst.ctypes.data, len(obst), C.byref(rng), C.byref(o),
                                    C.byref(st), C.byref(sob_idx))
@@ -275,6 +294,7 @@ def plan_dubins(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=
     res = dict(x=x[:n].copy(), y=y[:n].copy(), yaw=yaw[:n].copy(), cost=cost[:n].copy(), parent=parent[:n].copy(),
                poly_len=plen[:n].copy(), poly_x=ppx[:o.poly_n].copy(), poly_y=ppy[:o.poly_n].copy(),
                path=path[:o.path_n].copy() if o.path_n else None,
+               path_yaw=path_yaw[:o.path_n].copy() if o.path_n else None,
                stats={k: getattr(st, k) for k, _ in Stats._fields_}, rng=rng, sobol_index=int(sob_idx.value))
     if trace:
         t = o.tr_n

@@ -112,6 +112,31 @@ def test_dubins_rrt_star_oracle_matches_reference_golden(path):
     assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])
 
 
+@pytest.mark.parametrize("path", util.golden_files("rrt06"), ids=lambda p: p.split("/")[-1][:-4])
+def test_reeds_shepp_rrt_star_oracle_matches_reference_golden(path):
+    """rrt_06 RRT*-Reeds-Shepp (oracle only so far): poses, costs, parents incl. the try_goal_path
+    nodes, every stored edge polyline, the three-column final course and the RNG state."""
+    import oracle
+    g = util.load_golden(path)
+    r = oracle.plan_rrt_rs(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]), seed=int(g["seed"]),
+                           curvature=float(g["curvature"]), robot_radius=float(g["robot_radius"]),
+                           expand_dis=float(g["expand_dis"]), connect_circle_dist=float(g["connect_circle_dist"]),
+                           step_size=float(g["step_size"]), trace=True,
+                           search_until_max_iter=bool(int(g["search_until_max_iter"])))
+    util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(r["yaw"], g["yaw"])
+    assert np.array_equal(r["poly_len"], g["poly_len"]) and np.array_equal(r["poly_x"], g["poly_x"]) \
+        and np.array_equal(r["poly_y"], g["poly_y"])
+    if len(g["path"]) == 0:
+        assert r["path"] is None
+    else:
+        assert r["path"] is not None and np.array_equal(r["path"], g["path"][:, :2])
+        assert np.array_equal(r["path_yaw"], g["path"][:, 2])
+    assert r["rng"].pos == int(g["rng_pos_after"]) and r["rng"].mt[0] == int(g["rng_word0_after"])
+    n = len(g["tr_nearest"])
+    assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])
+
+
 @pytest.mark.parametrize("path", util.golden_files("rrt03"), ids=lambda p: p.split("/")[-1][:-4])
 def test_rrt_dubins_oracle_matches_reference_golden(path):
     """rrt_03 RRT with Dubins steer (pseudo-random and 3-D Sobol sampler): poses, Dubins-length costs, parents, every
