@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RRTX_ABI_VERSION 1
+#define RRTX_ABI_VERSION 2   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw */
 
 enum {
   RRTX_OK = 0,
@@ -43,14 +43,19 @@ enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
        RRTX_ALGO_DUBINS = 3,    /* rrt_05 RRT.planning :1416-1456 (RRT*-Dubins; start[2]/goal[2] = yaw) */
        RRTX_ALGO_BITSTAR = 4,   /* rrt_08 BITStar.plan :236-331 (max_iter = maxIter; rand_area = randArea) */
        RRTX_ALGO_RRT_DUBINS = 5 /* rrt_03 RRT.planning :1420-1456 (RRT with Dubins steer; poses, curvature and goal
-                                   thresholds as RRTX_ALGO_DUBINS; sampler SOBOL = the 3-D point of :1545-1563) */ };
+                                   thresholds as RRTX_ALGO_DUBINS; sampler SOBOL = the 3-D point of :1545-1563) */,
+       RRTX_ALGO_RS = 6         /* rrt_06 RRT.planning :1530-1570 (RRT*-Reeds-Shepp incl. try_goal_path :1572-1582; poses,
+                                   curvature, step_size and goal thresholds; node capacity 2 * max_iter + 2; the sampler is
+                                   always get_random_node :1658-1666, as in the reference's loop :1539) */ };
 enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
        RRTX_SAMPLER_SOBOL = 1   /* get_random_node_sobol  rrt_04:1142-1153 */ };
 
 /* per-instance status bits (rrtx_get_results) */
 enum { RRTX_ST_DONE = 1, RRTX_ST_PATH = 2, RRTX_ST_OVERFLOW = 4, RRTX_ST_PATH_TRUNC = 8,
        RRTX_ST_UNSUPPORTED = 16 /* a reference code path the device kernel does not restate was reached (see
-                                   rrtx_last_error); the instance stops there instead of continuing differently */ };
+                                   rrtx_last_error); the instance stops there instead of continuing differently */,
+       RRTX_ST_REF_RAISES = 32  /* RRTX_ALGO_RS: the reference raises here (ZeroDivisionError :1183/:1207 or ValueError from
+                                   math.acos/asin) inside reeds_shepp_path_planning; the instance stops, no path */ };
 
 /* Constructor arguments of the reference classes (rrt_04:951-1000, rrt_01:32-69). */
 typedef struct rrtx_params {
@@ -78,6 +83,9 @@ typedef struct rrtx_params {
   double informed_c_min;
   /* RRTX_ALGO_DUBINS / RRTX_ALGO_RRT_DUBINS only (rrt_05:1371-1373, 1411-1413; rrt_03:1381-1383, 1416-1418) */
   double curvature, goal_yaw_th, goal_xy_th;
+  /* RRTX_ALGO_RS only: step_size of the Reeds-Shepp interpolation (rrt_06:1484, :1525) */
+  double step_size;
+  double reserved_d[3];
 } rrtx_params;
 
 /* Aggregate counters over all instances of the last rrtx_plan(). */
@@ -139,6 +147,8 @@ int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes);
 /* RRTX_ALGO_DUBINS: node yaw (rrt_05 Node.yaw) and the stored edge polylines (Node.path_x / path_y, :1472-1474):
  * plen[i] points per node, concatenated in node order into px/py. */
 int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap);
+/* RRTX_ALGO_RS: third column of generate_final_course (rrt_06:1643-1651), same points as rrtx_get_path */
+int rrtx_get_path_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap_points, int32_t* n_out);
 int rrtx_get_polylines(rrtx_handle* h, int32_t instance, int32_t* plen, int32_t cap_nodes, double* px, double* py,
                        int64_t cap_points, int64_t* n_points_out);
 /* Sobol index (RRT.sobol_inter_, rrt_04:995,1148) after planning */

@@ -11,7 +11,7 @@ Submodules: planner (RRT = rrt_01's class, RRTStar = rrt_04's class, BatchPlanne
 _abi (ctypes binding of include/rrtx.h), csrc/ (HIP kernels + C ABI sources).
 """
 from . import _abi  # noqa: F401
-from .planner import (RRT, RRTSobol, RRTStar, RRTStarDubins, RRTDubins, BITStar, bitstar_rotation, InformedRRTStar, BatchPlanner, Node, AreaBounds, get_path_length, path_smoothing,  # noqa: F401
+from .planner import (RRT, RRTSobol, RRTStar, RRTStarDubins, RRTDubins, RRTStarReedsShepp, BITStar, bitstar_rotation, InformedRRTStar, BatchPlanner, Node, AreaBounds, get_path_length, path_smoothing,  # noqa: F401
                       informed_rotation)
 
-__all__ = ["RRT", "RRTSobol", "RRTStar", "RRTStarDubins", "RRTDubins", "BITStar", "InformedRRTStar", "BatchPlanner", "Node", "AreaBounds", "get_path_length", "path_smoothing"]
+__all__ = ["RRT", "RRTSobol", "RRTStar", "RRTStarDubins", "RRTDubins", "RRTStarReedsShepp", "BITStar", "InformedRRTStar", "BatchPlanner", "Node", "AreaBounds", "get_path_length", "path_smoothing"]

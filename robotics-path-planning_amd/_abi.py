@@ -12,8 +12,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
-RRTX_ABI_VERSION = 1
-ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR, ALGO_RRT_DUBINS = 0, 1, 2, 3, 4, 5
+RRTX_ABI_VERSION = 2
+ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR, ALGO_RRT_DUBINS, ALGO_RS = 0, 1, 2, 3, 4, 5, 6
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
 ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC = 1, 2, 4, 8
 ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
@@ -23,7 +23,7 @@ EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obs
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
-           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path"]
+           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw"]
 
 
 class Params(C.Structure):
@@ -37,7 +37,7 @@ class Params(C.Structure):
                 ("play_area", C.c_double * 4), ("robot_radius", C.c_double),
                 ("connect_circle_dist", C.c_double), ("informed_rot", C.c_double * 4),
                 ("informed_c_min", C.c_double), ("curvature", C.c_double), ("goal_yaw_th", C.c_double),
-                ("goal_xy_th", C.c_double)]
+                ("goal_xy_th", C.c_double), ("step_size", C.c_double), ("reserved_d", C.c_double * 3)]
 
 
 class Stats(C.Structure):
@@ -96,6 +96,7 @@ def load():
     L.rrtx_smooth_paths.argtypes = [i32, i32, vp, vp, i32, i32, vp, i32, vp, vp, vp, i32, vp, vp]
     L.rrtx_smooth_planned.argtypes = [vp, i32]
     L.rrtx_get_smoothed_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.rrtx_get_path_yaw.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     for f in EXPORTS:
         if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
             getattr(L, f).restype = C.c_int
@@ -111,7 +112,7 @@ class Handle:
     def __init__(self, algo, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
                  play_area=None, robot_radius=0.0, sampler=SAMPLER_MT, connect_circle_dist=50.0,
                  search_until_max_iter=False, n_instances=1, device=0, informed_rot=None, informed_c_min=0.0,
-                 curvature=1.0, goal_yaw_th=0.0, goal_xy_th=0.0):
+                 curvature=1.0, goal_yaw_th=0.0, goal_xy_th=0.0, step_size=0.0):
         self.L = load()
         p = Params()
         p.abi_version = RRTX_ABI_VERSION
@@ -136,6 +137,7 @@ class Handle:
                 p.informed_rot[i] = float(informed_rot[i])
         p.informed_c_min = float(informed_c_min)
         p.curvature, p.goal_yaw_th, p.goal_xy_th = float(curvature), float(goal_yaw_th), float(goal_xy_th)
+        p.step_size = float(step_size)
         self.params = p
         self.n_instances = int(n_instances)
         self.max_iter = int(max_iter)
@@ -218,6 +220,16 @@ class Handle:
         xy = np.zeros((n.value, 2))
         self._chk(self.L.rrtx_get_path(self._h, instance, xy.ctypes.data, n.value, C.byref(n)), "rrtx_get_path")
         return xy
+
+    def get_path_yaw(self, instance=0):
+        """RRTX_ALGO_RS: the yaw column of the final course (rrt_06:1643-1651), one value per point of get_path."""
+        n = C.c_int32()
+        self._chk(self.L.rrtx_get_path_yaw(self._h, instance, None, 0, C.byref(n)), "rrtx_get_path_yaw")
+        if n.value == 0:
+            return None
+        yaw = np.zeros(n.value)
+        self._chk(self.L.rrtx_get_path_yaw(self._h, instance, yaw.ctypes.data, n.value, C.byref(n)), "rrtx_get_path_yaw")
+        return yaw
 
     def get_results(self):
         B = self.n_instances

@@ -1,4 +1,4 @@
-// rpp_rs.h -- Reeds-Shepp steer primitive (host + device source): groundwork for rrt_06, not yet used by a kernel.
+// rpp_rs.h -- Reeds-Shepp steer primitive (host + device source) of rrt_06; used by rrt_rs.hip.h.
 // Reference: 10_path_planning_01_rrt_06_rrt_star_reeds_shepp_path.py -- reeds_shepp_path_planning :1426-1441,
 // calc_paths :1403-1424, generate_path :1286-1342 (12 word families x {identity, timeflip, reflect, both}),
 // set_path :1061-1080, mod2pi :1051-1059, polar :1082-1085, the word functions :1088-1269,
@@ -198,94 +198,163 @@ RPP_HD static inline void rs_interp(double dist, char mode, double maxc, double 
     *yaw = (mode == 'L') ? oyaw + dist : oyaw - dist;
   }
 }
-// reeds_shepp_path_planning :1426-1441; writes at most cap points
-RPP_HD static inline void rs_plan(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
-                                  double step_size, double* px, double* py, double* pyaw, int cap, RsResult* R) {
-  RsCand cand[RS_MAXP];
-  int np = 0;
-  R->n = 0;
-  R->err = 0;
-  R->nl = 0;
-  // generate_path :1286-1342
-  const double dx = gx - sx, dy = gy - sy, dth = gyaw - syaw;
+// ---- the solver in separable parts (the iteration kernel of rrt_06 runs them cooperatively; rs_plan below is the
+// same sequence on one thread, and is what the known-answer vectors pin) ----------------------------------------
+// local frame of generate_path :1286-1296
+struct RsFrame {
+  double x, y, dth, step;
+};
+RPP_HD static inline void rs_frame(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
+                                   double step_size, RsFrame* F) {
+  const double dx = gx - sx, dy = gy - sy;
+  F->dth = gyaw - syaw;
   const double c = rpp_glibc_cos(syaw), s = rpp_glibc_sin(syaw);
-  const double x = (c * dx + s * dy) * maxc, y = (-s * dx + c * dy) * maxc;
-  const double step = step_size * maxc;
-  for (int w = 0; w < 12; w++) {
-    for (int var = 0; var < 4; var++) {
-      const double xx = (var == 1 || var == 3) ? -x : x, yy = (var >= 2) ? -y : y;
-      const double pp = (var == 1 || var == 2) ? -dth : dth;
-      double d[5];
-      char ct[6];
-      int n = 0, err = 0;
-      if (!rs_word(w, xx, yy, pp, d, ct, &n, &err)) {
-        if (err) {
-          R->err = err;
-          return;
-        }
-        continue;
-      }
-      const double tot = rs_sum_abs(d, n);
-      for (int i = 0; i < n; i++)
-        if (0.1 * tot < dabs(d[i]) && dabs(d[i]) < step) return;   // "Step size too large" -> [] -> None
-      if (var == 1 || var == 3)
-        for (int i = 0; i < n; i++) d[i] = -d[i];                  // timeflip
-      if (var >= 2)
-        for (int i = 0; ct[i]; i++) ct[i] = (ct[i] == 'L') ? 'R' : (ct[i] == 'R' ? 'L' : 'S');   // reflect
-      // set_path :1061-1080
-      const double L = rs_sum_abs(d, n);
-      bool skip = false;
-      for (int i = 0; i < np; i++)
-        if (rs_same(cand[i].ct, ct) && (rs_sum_abs(cand[i].len, cand[i].nl) - L) <= step) skip = true;
-      if (skip || L <= step || np >= RS_MAXP) continue;
-      for (int i = 0; i < n; i++) cand[np].len[i] = d[i];
-      rs_ct(cand[np].ct, ct);
-      cand[np].nl = n;
-      cand[np].L = L;
-      np++;
-    }
+  F->x = (c * dx + s * dy) * maxc;
+  F->y = (-s * dx + c * dy) * maxc;
+  F->step = step_size * maxc;
+}
+// One (word family w, symmetry var) of generate_path :1298-1340.  Returns 0: no path from this variant, 1: a path
+// (d, ct, n filled, flips applied), 2: "Step size too large" (the reference returns [] there and then, :1071-1074),
+// < 0: the reference raises.
+RPP_HD static inline int rs_variant(int w, int var, const RsFrame& F, double* d, char* ct, int* n) {
+  const double xx = (var == 1 || var == 3) ? -F.x : F.x, yy = (var >= 2) ? -F.y : F.y;
+  const double pp = (var == 1 || var == 2) ? -F.dth : F.dth;
+  int err = 0;
+  *n = 0;
+  if (!rs_word(w, xx, yy, pp, d, ct, n, &err)) return err ? err : 0;
+  const double tot = rs_sum_abs(d, *n);
+  for (int i = 0; i < *n; i++)
+    if (0.1 * tot < dabs(d[i]) && dabs(d[i]) < F.step) return 2;
+  if (var == 1 || var == 3)
+    for (int i = 0; i < *n; i++) d[i] = -d[i];                  // timeflip
+  if (var >= 2)
+    for (int i = 0; ct[i]; i++) ct[i] = (ct[i] == 'L') ? 'R' : (ct[i] == 'R' ? 'L' : 'S');   // reflect
+  return 1;
+}
+// set_path :1061-1080 over the variants in the reference's order + `paths.index(min(...))` :1436.
+// st[k], d[k][5], ct[k][6], n[k] for k = 4 * w + var.  Returns the chosen k, -1: None, < -1: the reference raises.
+template <typename D5, typename C6>
+RPP_HD static inline int rs_select(const int32_t* st, const D5* d, const C6* ct, const int32_t* n, double step,
+                                   double maxc) {
+  int kept[RS_MAXP];
+  double keptL[RS_MAXP];
+  int np = 0;
+  for (int k = 0; k < 48; k++) {
+    if (st[k] == 0) continue;
+    if (st[k] < 0) return st[k];   // -3 / -4
+    if (st[k] == 2) return -1;
+    const double L = rs_sum_abs(d[k], n[k]);
+    bool skip = false;
+    for (int i = 0; i < np; i++)
+      if (rs_same(ct[kept[i]], ct[k]) && (keptL[i] - L) <= step) skip = true;
+    if (skip || L <= step || np >= RS_MAXP) continue;
+    kept[np] = k;
+    keptL[np] = L;
+    np++;
   }
-  if (np == 0) return;
+  if (np == 0) return -1;
   int bi = 0;
-  double bl = dabs(cand[0].L / maxc);
-  for (int i = 1; i < np; i++) {   // paths.index(min(paths, key=abs(L))) :1436
-    const double l = dabs(cand[i].L / maxc);
+  double bl = dabs(keptL[0] / maxc);
+  for (int i = 1; i < np; i++) {
+    const double l = dabs(keptL[i] / maxc);
     if (l < bl) {
       bl = l;
       bi = i;
     }
   }
-  const RsCand& P = cand[bi];
-  // generate_local_course :1355-1377 + global conversion :1411-1417
-  const double cg = rpp_glibc_cos(-syaw), sg = rpp_glibc_sin(-syaw);
+  return kept[bi];
+}
+// generate_local_course :1355-1377 prepared for random access: segment origins, np.arange counts
+struct RsCourse {
+  double len[5], ddist[5];
+  double ox[5], oy[5], oyaw[5];
+  int32_t cnt[5];      // arange points of the segment; the segment has cnt + 1 points (np.append(.., length))
+  int32_t first[6];    // index of the segment's first point in the polyline
+  char ct[6];
+  int32_t nl, total;
+  double sx, sy, syaw, cg, sg, maxc;
+};
+RPP_HD static inline void rs_course(const double* len, const char* ct, int nl, double sx, double sy, double syaw,
+                                    double maxc, double step_size, RsCourse* C) {
+  C->cg = rpp_glibc_cos(-syaw);
+  C->sg = rpp_glibc_sin(-syaw);
+  C->sx = sx;
+  C->sy = sy;
+  C->syaw = syaw;
+  C->maxc = maxc;
+  C->nl = nl;
   double ox = 0.0, oy = 0.0, oyaw = 0.0;
   const double ds = step_size * maxc;
-  int n = 0;
-  for (int sgm = 0; sgm < P.nl; sgm++) {
-    const double length = P.len[sgm];
-    const char md = P.ct[sgm];
+  int tot = 0;
+  for (int sgm = 0; sgm < nl; sgm++) {
+    const double length = len[sgm];
     const double d_dist = length >= 0.0 ? ds : -ds;
     const double q = (length - 0.0) / d_dist;            // np.arange(0.0, length, d_dist)
     const long cnt = (q > 0.0) ? (long)__builtin_ceil(q) : 0;
-    double lx = ox, ly = oy, lyaw = oyaw;
-    for (long i = 0; i <= cnt; i++) {
-      const double dist = (i < cnt) ? 0.0 + (double)i * d_dist : length;   // np.append(interp_dists, length)
-      rs_interp(dist, md, maxc, ox, oy, oyaw, &lx, &ly, &lyaw);
-      if (n < cap) {
-        px[n] = cg * lx + sg * ly + sx;
-        py[n] = -sg * lx + cg * ly + sy;
-        pyaw[n] = angle_mod_pi(lyaw + syaw);
-      }
-      n++;
-    }
+    C->len[sgm] = length;
+    C->ddist[sgm] = d_dist;
+    C->ct[sgm] = ct[sgm];
+    C->ox[sgm] = ox;
+    C->oy[sgm] = oy;
+    C->oyaw[sgm] = oyaw;
+    C->cnt[sgm] = (int32_t)cnt;
+    C->first[sgm] = tot;
+    tot += (int32_t)cnt + 1;
+    double lx, ly, lyaw;
+    rs_interp(length, ct[sgm], maxc, ox, oy, oyaw, &lx, &ly, &lyaw);   // the segment's last point = next origin
     ox = lx;
     oy = ly;
     oyaw = lyaw;
   }
-  for (int i = 0; i < P.nl; i++) R->len[i] = P.len[i] / maxc;
-  rs_ct(R->ct, P.ct);
-  R->nl = P.nl;
-  R->n = n;
+  C->ct[nl] = 0;
+  C->first[nl] = tot;
+  C->total = tot;
+}
+// world-frame point k of the course (:1411-1417)
+RPP_HD static inline void rs_point(const RsCourse& C, int k, double* wx, double* wy, double* wyaw) {
+  int sgm = 0;
+  while (sgm + 1 < C.nl && k >= C.first[sgm + 1]) sgm++;
+  const int i = k - C.first[sgm];
+  const double dist = (i < C.cnt[sgm]) ? 0.0 + (double)i * C.ddist[sgm] : C.len[sgm];
+  double lx, ly, lyaw;
+  rs_interp(dist, C.ct[sgm], C.maxc, C.ox[sgm], C.oy[sgm], C.oyaw[sgm], &lx, &ly, &lyaw);
+  *wx = C.cg * lx + C.sg * ly + C.sx;
+  *wy = -C.sg * lx + C.cg * ly + C.sy;
+  *wyaw = angle_mod_pi(lyaw + C.syaw);
+}
+// reeds_shepp_path_planning :1426-1441; writes at most cap points
+RPP_HD static inline void rs_plan(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
+                                  double step_size, double* px, double* py, double* pyaw, int cap, RsResult* R) {
+  R->n = 0;
+  R->err = 0;
+  R->nl = 0;
+  RsFrame F;
+  rs_frame(sx, sy, syaw, gx, gy, gyaw, maxc, step_size, &F);
+  int32_t st[48], n[48];
+  double d[48][5];
+  char ct[48][6];
+  for (int k = 0; k < 48; k++) {
+    int nn = 0;
+    st[k] = rs_variant(k >> 2, k & 3, F, d[k], ct[k], &nn);
+    n[k] = nn;
+    if (st[k] < 0 || st[k] == 2) {   // the reference stops here; nothing later is looked at
+      for (int q = k + 1; q < 48; q++) st[q] = 0;
+      break;
+    }
+  }
+  const int sel = rs_select(st, d, ct, n, F.step, maxc);
+  if (sel < -1) {
+    R->err = sel;
+    return;
+  }
+  if (sel < 0) return;
+  RsCourse C;
+  rs_course(d[sel], ct[sel], n[sel], sx, sy, syaw, maxc, step_size, &C);
+  for (int k = 0; k < C.total && k < cap; k++) rs_point(C, k, &px[k], &py[k], &pyaw[k]);
+  for (int i = 0; i < n[sel]; i++) R->len[i] = d[sel][i] / maxc;
+  rs_ct(R->ct, ct[sel]);
+  R->nl = n[sel];
+  R->n = C.total;
 }
 
 }  // namespace rpp

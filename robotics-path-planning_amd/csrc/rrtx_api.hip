@@ -17,6 +17,7 @@
 #include "rrt_star_v2.hip.h"
 #include "rrt_informed.hip.h"
 #include "rrt_dubins.hip.h"
+#include "rrt_rs.hip.h"
 #include "rrt_bitstar.hip.h"
 #include "rrt_bitstar_wave.hip.h"
 #include "path_smooth.hip.h"
@@ -115,12 +116,15 @@ void rrtx_destroy(rrtx_handle* h) {
 }
 
 static inline bool is_dubins(int algo) { return algo == RRTX_ALGO_DUBINS || algo == RRTX_ALGO_RRT_DUBINS; }
+// planners whose nodes are poses with a stored edge polyline (rrt_03 / rrt_05 / rrt_06)
+static inline bool is_pose_tree(int algo) { return is_dubins(algo) || algo == RRTX_ALGO_RS; }
 
 int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   if (!p || !out) return RRTX_E_INVALID;
   *out = nullptr;
   if (p->abi_version != RRTX_ABI_VERSION) return RRTX_E_INVALID;
-  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS && p->algo != RRTX_ALGO_BITSTAR && p->algo != RRTX_ALGO_RRT_DUBINS) return RRTX_E_INVALID;
+  if (p->algo != RRTX_ALGO_RRT && p->algo != RRTX_ALGO_RRT_STAR && p->algo != RRTX_ALGO_INFORMED && p->algo != RRTX_ALGO_DUBINS && p->algo != RRTX_ALGO_BITSTAR && p->algo != RRTX_ALGO_RRT_DUBINS && p->algo != RRTX_ALGO_RS) return RRTX_E_INVALID;
+  if (p->algo == RRTX_ALGO_RS && (!(p->step_size > 0.0) || !(p->curvature > 0.0))) return RRTX_E_INVALID;
   if (p->n_instances < 1 || p->max_iter < 0 || !(p->path_resolution > 0.0) || !(p->expand_dis >= 0.0))
     return RRTX_E_INVALID;
   int ndev = 0;
@@ -142,7 +146,8 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   HIPCHK(h, hipEventCreate(&h->ev0));
   HIPCHK(h, hipEventCreate(&h->ev1));
   // node capacity: start + one node per iteration; padded so each wave's 512-node stride stays inside
-  const int64_t cap = (int64_t)p->max_iter + 2;
+  // (rrt_06: try_goal_path :1572-1582 can append a second node per iteration)
+  const int64_t cap = (p->algo == RRTX_ALGO_RS ? 2 : 1) * (int64_t)p->max_iter + 2;
   h->stride = (cap + 511) / 512 * 512 + 2560;
   const size_t tot = (size_t)h->stride * h->n_inst;
   Ctx& c = h->c;
@@ -232,25 +237,36 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     }
   }
   memset(&h->da, 0, sizeof(h->da));
-  if (is_dubins(p->algo)) {
+  if (is_pose_tree(p->algo)) {
     rppd::DubArgs& d = h->da;
     d.plain = p->algo == RRTX_ALGO_RRT_DUBINS;
-    d.pool_cap = 128 * cap + 4096;   // polyline points per instance (edges replaced by rewire stay allocated)
+    // polyline points per instance (edges replaced by rewire stay allocated; rrt_06 edges run all the way to the
+    // sample at step_size spacing and are longer)
+    d.pool_cap = (p->algo == RRTX_ALGO_RS ? 160 : 128) * cap + 8192;
     if ((rc = dalloc(h, &d.yaw, tot))) return rc;
     if ((rc = dalloc(h, &d.poff, tot))) return rc;
     if ((rc = dalloc(h, &d.plen, tot))) return rc;
     if ((rc = dalloc(h, &d.pool_x, (size_t)d.pool_cap * h->n_inst))) return rc;
     if ((rc = dalloc(h, &d.pool_y, (size_t)d.pool_cap * h->n_inst))) return rc;
     if ((rc = dalloc(h, &d.pool_used, h->n_inst))) return rc;
-    if ((rc = dalloc(h, &d.spx, (size_t)rppd::PMAX * h->n_inst))) return rc;
-    if ((rc = dalloc(h, &d.spy, (size_t)rppd::PMAX * h->n_inst))) return rc;
-    if ((rc = dalloc(h, &d.plans, (size_t)rppd::NUD * h->n_inst))) return rc;
-    if ((rc = dalloc(h, &d.rawslot, tot))) return rc;
     d.curvature = p->curvature;
     d.goal_yaw_th = p->goal_yaw_th;
     d.goal_xy_th = p->goal_xy_th;
     d.start_yaw = p->start[2];
     d.goal_yaw = p->goal[2];
+  }
+  if (p->algo == RRTX_ALGO_RS) {
+    rppd::DubArgs& d = h->da;
+    d.step_size = p->step_size;
+    if ((rc = dalloc(h, &d.pool_yaw, (size_t)d.pool_cap * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.dscr, tot))) return rc;
+  }
+  if (is_dubins(p->algo)) {
+    rppd::DubArgs& d = h->da;
+    if ((rc = dalloc(h, &d.spx, (size_t)rppd::PMAX * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.spy, (size_t)rppd::PMAX * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.plans, (size_t)rppd::NUD * h->n_inst))) return rc;
+    if ((rc = dalloc(h, &d.rawslot, tot))) return rc;
   }
   HIPCHK(h, hipMemcpy(dr2, r2.data(), r2.size() * sizeof(double), hipMemcpyHostToDevice));
   // default per-instance state: ctor start/goal, RNG seeded with the instance number
@@ -271,6 +287,10 @@ int rrtx_set_obstacles(rrtx_handle* h, const double* oxyr, int32_t m) {
   if (!h || m < 0 || (m > 0 && !oxyr)) return RRTX_E_INVALID;
   if (m > rppk::MAX_OBS) {
     h->err = "more than 256 obstacles";
+    return RRTX_E_INVALID;
+  }
+  if (h->p.algo == RRTX_ALGO_RS && m > rppr::MAX_OBS) {
+    h->err = "RRTX_ALGO_RS: more than 64 obstacles";
     return RRTX_E_INVALID;
   }
   std::vector<double> ox(rppk::MAX_OBS, 0.0), oy(rppk::MAX_OBS, 0.0), th(rppk::MAX_OBS, -1.0);
@@ -498,7 +518,7 @@ int rrtx_plan(rrtx_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));   // `inf` is a local
   }
   // on the handle's own stream: it is a non-blocking stream, work queued on the null stream is not ordered with it
-  if (is_dubins(c.algo)) HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
+  if (is_pose_tree(c.algo)) HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
   rppi::InformedArgs ia;
   for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
   ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
@@ -511,6 +531,8 @@ int rrtx_plan(rrtx_handle* h) {
                          h->chunk_iters);
     else if (is_dubins(c.algo))
       hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(B), dim3(rppd::TPB), 0, h->stream, c, h->da, h->chunk_iters);
+    else if (c.algo == RRTX_ALGO_RS)
+      hipLaunchKernelGGL(rppr::rrt_rs_kernel, dim3(B), dim3(rppr::TPB), 0, h->stream, c, h->da, h->chunk_iters);
     else
       hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(B), dim3(rppk::TPB), 0, h->stream, c, h->chunk_iters);
     HIPCHK(h, hipGetLastError());
@@ -539,7 +561,7 @@ int rrtx_plan(rrtx_handle* h) {
   rrtx_stats& s = h->stats;
   memset(&s, 0, sizeof(s));
   memset(h->phase, 0, sizeof(h->phase));
-  bool overflow = false, unsupported = false;
+  bool overflow = false, unsupported = false, raises = false;
   for (int i = 0; i < B; i++) {
     const Inst& I = back[i];
     s.iterations += I.iterations;
@@ -559,6 +581,7 @@ int rrtx_plan(rrtx_handle* h) {
     if (I.nu_max > s.near_unique_max) s.near_unique_max = I.nu_max;
     if (I.status & RRTX_ST_OVERFLOW) overflow = true;
     if (I.status & RRTX_ST_UNSUPPORTED) unsupported = true;
+    if (I.status & RRTX_ST_REF_RAISES) raises = true;
     for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];
   }
   s.launches = launches;
@@ -568,6 +591,11 @@ int rrtx_plan(rrtx_handle* h) {
   if (overflow) {
     h->err = "a fixed on-device capacity was exceeded (near-candidate list NU_MAX, polyline pool, or a BIT* slab)";
     return RRTX_E_OVERFLOW;
+  }
+  if (raises) {
+    h->err = "rrt_06: the reference raises inside reeds_shepp_path_planning for at least one instance (status bit "
+             "RRTX_ST_REF_RAISES; ZeroDivisionError :1183/:1207 or a math domain error); those instances have no result";
+    return RRTX_E_STATE;
   }
   if (unsupported) {
     h->err = "rrt_04 rewire: a node moved by an unsnapped steer is listed again in near_inds (distance tie); the "
@@ -640,7 +668,7 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
     HIPCHK(h, hipMemcpy(xy, d, sizeof(double) * 2 * oi[3], hipMemcpyDeviceToHost));
     return RRTX_OK;
   }
-  if (is_dubins(h->p.algo)) {
+  if (is_pose_tree(h->p.algo)) {
     // generate_final_course (rrt_05:1512-1521): [goal] + reversed edge polylines up the parent chain + [start]
     const int n = I.n;
     const int64_t off = (int64_t)instance * h->stride;
@@ -728,7 +756,7 @@ int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes) {
 
 int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap) {
   if (!h || !yaw || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
-  if (!h->planned || !is_dubins(h->p.algo)) return RRTX_E_STATE;
+  if (!h->planned || !is_pose_tree(h->p.algo)) return RRTX_E_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   Result r;
   HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));
@@ -737,10 +765,44 @@ int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap) {
   return RRTX_OK;
 }
 
+int rrtx_get_path_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap_points, int32_t* n_out) {
+  if (!h || instance < 0 || instance >= h->n_inst || !n_out) return RRTX_E_INVALID;
+  if (!h->planned || h->p.algo != RRTX_ALGO_RS) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Inst I;
+  HIPCHK(h, hipMemcpy(&I, h->c.inst + instance, sizeof(I), hipMemcpyDeviceToHost));
+  *n_out = 0;
+  if (!(I.status & RRTX_ST_PATH)) return RRTX_OK;
+  // generate_final_course (rrt_06:1643-1651): [goal yaw] + reversed edge-polyline yaws up the parent chain + [start yaw]
+  const int n = I.n;
+  const int64_t off = (int64_t)instance * h->stride;
+  std::vector<int32_t> par(n), plen(n);
+  std::vector<int64_t> poff(n);
+  HIPCHK(h, hipMemcpy(par.data(), h->c.parent + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(plen.data(), h->da.plen + off, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(poff.data(), h->da.poff + off, sizeof(int64_t) * n, hipMemcpyDeviceToHost));
+  int64_t total = 2;
+  for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) total += plen[nd];
+  *n_out = (int32_t)total;
+  if (!yaw) return RRTX_OK;
+  if (cap_points < total) return RRTX_E_CAPACITY;
+  int64_t k = 0;
+  yaw[k++] = h->p.goal[2];
+  std::vector<double> bw;
+  for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) {
+    bw.resize(plen[nd]);
+    HIPCHK(h, hipMemcpy(bw.data(), h->da.pool_yaw + (int64_t)instance * h->da.pool_cap + poff[nd],
+                        sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
+    for (int q = plen[nd] - 1; q >= 0; q--) yaw[k++] = bw[q];
+  }
+  yaw[k] = h->p.start[2];
+  return RRTX_OK;
+}
+
 int rrtx_get_polylines(rrtx_handle* h, int32_t instance, int32_t* plen, int32_t cap_nodes, double* px, double* py,
                        int64_t cap_points, int64_t* n_points_out) {
   if (!h || !n_points_out || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
-  if (!h->planned || !is_dubins(h->p.algo)) return RRTX_E_STATE;
+  if (!h->planned || !is_pose_tree(h->p.algo)) return RRTX_E_STATE;
   HIPCHK(h, hipSetDevice(h->device));
   Result r;
   HIPCHK(h, hipMemcpy(&r, h->c.results + instance, sizeof(r), hipMemcpyDeviceToHost));

@@ -468,6 +468,47 @@ class RRTDubins(RRTStarDubins):
             self.sobol_inter_ = h.get_sobol_index(0)
 
 
+class RRTStarReedsShepp(RRTStarDubins):
+    """Drop-in for rrt_06's `RRT` (10_path_planning_01_rrt_06_rrt_star_reeds_shepp_path.py:1444-1914): RRT* whose steer
+    is the whole Reeds-Shepp path to the sample (:1584-1604), with `try_goal_path` (:1572-1582) after every accepted
+    node.  `planning(animation, search_until_max_iter=True)` as the driver calls it (:2087: the constructor's
+    `search_until_max_iter` is not read by the loop); the sampler is always `get_random_node` (:1539) and edge costs in
+    choose_parent / rewire are Euclidean (the last-defined calc_new_cost, :1901).  Returns the three-column course
+    `[[x, y, yaw], ...]` of generate_final_course (:1643-1651)."""
+
+    def __init__(self, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
+                 goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=True,
+                 connect_circle_dist=50.0, search_until_max_iter=False, curvature=1.0,
+                 goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.2, device=0):
+        super().__init__(start, goal, obstacle_list, rand_area, expand_dis=expand_dis, path_resolution=path_resolution,
+                         goal_sample_rate=goal_sample_rate, max_iter=max_iter, play_area=play_area,
+                         robot_radius=robot_radius, sobol_sampler=sobol_sampler, connect_circle_dist=connect_circle_dist,
+                         search_until_max_iter=search_until_max_iter, curvature=curvature, goal_yaw_th=goal_yaw_th,
+                         goal_xy_th=goal_xy_th, device=device)
+        self.step_size = step_size
+        self.path_yaw = None
+
+    def planning(self, animation=True, search_until_max_iter=True):
+        self.path_yaw = None
+        path = super().planning(animation, search_until_max_iter)
+        if path is None:
+            return None
+        return [[p[0], p[1], float(w)] for p, w in zip(path, self.path_yaw)]
+
+    plan = planning
+
+    def _make_handle(self, until_max=True):
+        return _abi.Handle(_abi.ALGO_RS, [self.start.x, self.start.y, self.start.yaw],
+                           [self.end.x, self.end.y, self.end.yaw], [self.min_rand, self.max_rand], self.expand_dis,
+                           self.path_resolution, self.goal_sample_rate, self.max_iter, robot_radius=self.robot_radius,
+                           connect_circle_dist=self.connect_circle_dist, search_until_max_iter=until_max, n_instances=1,
+                           device=self.device, curvature=self.curvature, goal_yaw_th=self.goal_yaw_th,
+                           goal_xy_th=self.goal_xy_th, step_size=self.step_size)
+
+    def _after_plan(self, h):
+        self.path_yaw = h.get_path_yaw(0)
+
+
 def path_smoothing(path, max_iter, obstacle_list, device=0):
     """Drop-in for rrt_04's module function `path_smoothing(path, max_iter, obstacle_list)` (:1447-1479): random
     shortcutting of the path `planning()` returned, drawing from CPython's global `random` stream (left exactly where

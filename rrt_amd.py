@@ -14,6 +14,7 @@ RRTStar = _pkg.RRTStar
 RRTSobol = _pkg.RRTSobol
 RRTStarDubins = _pkg.RRTStarDubins
 RRTDubins = _pkg.RRTDubins
+RRTStarReedsShepp = _pkg.RRTStarReedsShepp
 path_smoothing = _pkg.path_smoothing
 BITStar = _pkg.BITStar
 bitstar_rotation = _pkg.bitstar_rotation

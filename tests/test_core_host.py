@@ -46,7 +46,7 @@ def test_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(so)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.rrtx_abi_version() == 1
+    assert lib.rrtx_abi_version() == 2
     import rrt_amd
     assert set(rrt_amd._abi.EXPORTS) <= declared
 

@@ -301,6 +301,83 @@ def test_gpu_dubins_matches_reference_golden(gpu, path):
     assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
 
 
+@pytest.mark.parametrize("path", util.golden_files("rrt06"), ids=lambda p: p.split("/")[-1][:-4])
+def test_gpu_reeds_shepp_matches_reference_golden(gpu, path):
+    """rrt_06 RRT*-Reeds-Shepp on the GPU vs the reference goldens: poses, costs, parents (incl. the try_goal_path
+    nodes), every stored edge polyline, the three-column final course and the RNG state (ints exact; doubles
+    bit-exact on this image, contract 1e-6)."""
+    g = util.load_golden(path)
+    out = util.run_gpu_rrt_rs(g, [int(g["seed"])], trace_instance=0)
+    d = util.first_trace_divergence(out["trace"], g["tr_rx"], g["tr_ry"], g["tr_nearest"])
+    assert d is None, "first divergent iteration %d" % d
+    x, y, cost, parent = out["trees"][0]
+    assert len(x) == len(g["x"]) and np.array_equal(parent, g["parent"])
+    assert np.allclose(x, g["x"], rtol=0, atol=1e-6) and np.allclose(out["yaws"][0], g["yaw"], rtol=0, atol=1e-6)
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(out["yaws"][0], g["yaw"])
+    plen, px, py = out["polys"][0]
+    assert np.array_equal(plen, g["poly_len"]) and np.array_equal(px, g["poly_x"]) and np.array_equal(py, g["poly_y"])
+    p = out["paths"][0]
+    if len(g["path"]) == 0:
+        assert p is None
+    else:
+        assert p is not None and np.array_equal(p, g["path"][:, :2])
+        assert np.array_equal(out["path_yaws"][0], g["path"][:, 2])
+    st = out["rng"][0]
+    assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
+
+
+def _orc06(a):
+    import oracle
+    g, sd, it = a
+    r = oracle.plan_rrt_rs(g["start"], g["goal"], g["obstacles"], g["rand_area"], it, seed=sd,
+                           curvature=float(g["curvature"]), robot_radius=float(g["robot_radius"]),
+                           expand_dis=float(g["expand_dis"]), connect_circle_dist=float(g["connect_circle_dist"]),
+                           step_size=float(g["step_size"]))
+    return r["x"], r["y"], r["cost"], r["parent"], r["yaw"], r["poly_x"], r["path"], r["path_yaw"]
+
+
+def test_gpu_reeds_shepp_many_seeds_equal_oracle(gpu):
+    """96 seeds x the driver's 750 iterations (rrt_06:2012-2083) in one launch vs the oracle (itself pinned by the
+    goldens): trees, yaws, polylines and final courses."""
+    from concurrent.futures import ProcessPoolExecutor
+    g = {k: v for k, v in util.load_golden(util.GOLDEN + "/rrt06_drv_s7_it750.npz").items()}
+    seeds = list(range(100, 196))
+    out = util.run_gpu_rrt_rs(g, seeds)
+    with ProcessPoolExecutor(max_workers=8) as ex:
+        refs = list(ex.map(_orc06, [(g, s, 750) for s in seeds]))
+    found = 0
+    for i, s in enumerate(seeds):
+        r = refs[i]
+        util.assert_tree_equal(out["trees"][i], r[:4], "seed %d" % s)
+        assert np.array_equal(out["yaws"][i], r[4]) and np.array_equal(out["polys"][i][1], r[5])
+        assert (out["paths"][i] is None) == (r[6] is None)
+        if r[6] is not None:
+            found += 1
+            assert np.array_equal(out["paths"][i], r[6]) and np.array_equal(out["path_yaws"][i], r[7])
+    assert found > 48
+
+
+def test_reeds_shepp_host_class_drop_in(gpu):
+    """The rrt_06 driver (:2012-2087) through the drop-in class: same constructor arguments, same `random` stream."""
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt06_drv_s42_it200.npz")
+    random.seed(42)
+    rrt = rrt_amd.RRTStarReedsShepp(start=list(g["start"]), goal=list(g["goal"]),
+                                    obstacle_list=[tuple(o) for o in g["obstacles"]], rand_area=list(g["rand_area"]),
+                                    expand_dis=3.0, path_resolution=0.5, goal_sample_rate=10, max_iter=200,
+                                    play_area=None, robot_radius=0.6, sobol_sampler=True, connect_circle_dist=50.0,
+                                    search_until_max_iter=False, curvature=2.0, goal_yaw_th=float(np.deg2rad(1.0)),
+                                    goal_xy_th=0.5, step_size=0.1)
+    path = rrt.planning(animation=False)
+    assert path is not None and np.array_equal(np.array(path), g["path"])
+    assert len(rrt.node_list) == len(g["x"]) and rrt.node_list[3].cost == float(g["cost"][3])
+    assert random.getstate()[1][624] == int(g["rng_pos_after"])
+    smoothed = rrt_amd.path_smoothing([[a, b] for a, b, _ in path], 100, [tuple(o) for o in g["obstacles"]])
+    assert len(smoothed) >= 2 and smoothed[0] == [float(g["goal"][0]), float(g["goal"][1])]
+
+
 def test_gpu_dubins_batch_equals_oracle(gpu):
     import oracle
     g = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it500.npz")

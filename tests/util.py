@@ -213,6 +213,37 @@ def run_gpu_rrt_dubins(g, seeds, device=0, trace_instance=None):
     return out
 
 
+def run_gpu_rrt_rs(g, seeds, device=0, trace_instance=None):
+    """RRT*-Reeds-Shepp (rrt_06) instances on the GPU through the C ABI; g = golden dict (parameters)."""
+    import rrt_amd
+    A = rrt_amd._abi
+    h = A.Handle(A.ALGO_RS, [float(v) for v in g["start"]], [float(v) for v in g["goal"]],
+                 [float(v) for v in g["rand_area"]], float(g["expand_dis"]), 0.5, 10, int(g["max_iter"]),
+                 robot_radius=float(g["robot_radius"]), connect_circle_dist=float(g["connect_circle_dist"]),
+                 search_until_max_iter=bool(int(g.get("search_until_max_iter", 1))), n_instances=len(seeds),
+                 device=device, curvature=float(g["curvature"]), goal_yaw_th=float(g["goal_yaw_th"]),
+                 goal_xy_th=float(g["goal_xy_th"]), step_size=float(g["step_size"]))
+    try:
+        h.set_obstacles([tuple(float(v) for v in o) for o in g["obstacles"]])
+        h.seed_instances(seeds)
+        if trace_instance is not None:
+            h.enable_trace(trace_instance)
+        h.plan()
+        out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], yaws=[], polys=[], paths=[], path_yaws=[], rng=[])
+        for i in range(len(seeds)):
+            out["trees"].append(h.get_tree(i))
+            out["yaws"].append(h.get_yaw(i))
+            out["polys"].append(h.get_polylines(i))
+            out["paths"].append(h.get_path(i))
+            out["path_yaws"].append(h.get_path_yaw(i))
+            out["rng"].append(h.get_rng_state(i))
+        if trace_instance is not None:
+            out["trace"] = h.get_trace()
+    finally:
+        h.close()
+    return out
+
+
 def run_gpu_bitstar(obstacles, rand_area, max_iter, seeds, starts, goals, device=0, trace_instance=None):
     """BIT* (rrt_08) instances on the GPU through the C ABI; per-instance start / goal / rotation."""
     import rrt_amd
