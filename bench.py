@@ -39,11 +39,12 @@ def main():
                     help="planning instances per GPU (weak scaling)")
     ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
     ap.add_argument("--obstacles", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "c6"],
                     help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations (the headline metric); c3: rrt_07 Informed RRT* "
                          "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 1024 instances; "
                          "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1536 instances; "
-                         "c4: rrt_08 BIT*, driver constants, per-instance start/goal (SURVEY 8d), 80 iterations")
+                         "c4: rrt_08 BIT*, driver constants, per-instance start/goal (SURVEY 8d), 80 iterations; "
+                         "c6: rrt_06 RRT*-Reeds-Shepp, driver constants, 750 iterations / 4096 instances")
     ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
@@ -57,10 +58,17 @@ def main():
     import numpy as np
     import util
     c3 = a.workload == "c3"
-    c5 = a.workload == "c5"
+    c6 = a.workload == "c6"
+    c5 = a.workload == "c5" or c6     # c6 shares c5's reporting; only the planner and its constants differ
     if a.obstacles is None:
-        a.obstacles = 200 if c3 else (6 if c5 else 50)
-    if c5:
+        a.obstacles = 200 if c3 else ((7 if c6 else 6) if c5 else 50)
+    if c6:
+        if "--max-iter" not in sys.argv:
+            a.max_iter = 750
+        if "--instances" not in sys.argv:
+            a.instances = 4096      # two rounds of 8 waves per CU
+        a.warmup_max_iter = 0
+    if c5 and not c6:
         if "--max-iter" not in sys.argv:
             a.max_iter = 5000
         if "--instances" not in sys.argv:
@@ -102,12 +110,20 @@ def main():
         kw = dict(algo="dubins", start=[0.0, 0.0, 0.0], goal=[10.0, 10.0, 0.0],
                   obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)], rand_area=[-2, 15],
                   expand_dis=3.0, goal_sample_rate=10, max_iter=a.max_iter)
+    if c6:   # rrt_06 driver constants (rrt_06:2012-2083)
+        kw = dict(algo="rs", start=[0.0, 0.0, 0.0], goal=[10.0, 9.0, 0.0],
+                  obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)],
+                  rand_area=[-2, 15], expand_dis=3.0, goal_sample_rate=10, max_iter=a.max_iter)
     B = a.instances
     seeds = sharding.shard_seeds(rank, B)          # rank r owns seeds r*B+1 .. (r+1)*B, no exchange while planning
     cuda = torch.device("cuda", local_rank) if dist is not None else None
 
     def make_handle(max_iter):
-        if c5:
+        if c6:
+            h = A.Handle(A.ALGO_RS, kw["start"], kw["goal"], kw["rand_area"], 3.0, 0.5, 10, max_iter, robot_radius=0.6,
+                         connect_circle_dist=50.0, search_until_max_iter=True, n_instances=B, device=device,
+                         curvature=2.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.1)
+        elif c5:
             h = A.Handle(A.ALGO_DUBINS, kw["start"], kw["goal"], kw["rand_area"], 3.0, 0.5, 10, max_iter, robot_radius=0.0,
                          connect_circle_dist=50.0, search_until_max_iter=True, n_instances=B, device=device,
                          curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5)
@@ -204,13 +220,15 @@ def main():
             # final_path_cost_mean / _min below
             "metric": "%s edge expansions/sec + final path cost, %s tree (collision-checked edges evaluated on the "
                       "device, distinct per iteration; %d iterations)"
-                      % ("RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"),
+                      % ("RRT*-Reeds-Shepp" if c6 else "RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"),
                          "100k-node" if (not c3 and not c5 and a.max_iter >= 100000) else "%d-iteration" % a.max_iter,
                          a.max_iter),
             "value": value, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": steps_done, "warmup": a.warmup,
             "ms_per_step": 1e3 * tmax / max(steps_done, 1), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("C5: rrt_05 RRT*-Dubins, driver constants (%d obstacles, 17x17 area, curvature 1), "
+            "config": {"workload": ("C6: rrt_06 RRT*-Reeds-Shepp, driver constants (%d obstacles, 17x17 area, curvature 2, "
+                                    "step_size 0.1, robot_radius 0.6), max_iter %d, %d instances/GPU (seeds 1..)" if c6 else
+                                    "C5: rrt_05 RRT*-Dubins, driver constants (%d obstacles, 17x17 area, curvature 1), "
                                     "max_iter %d, %d instances/GPU (seeds 1..)" if c5 else
                                     "C3: rrt_07 Informed RRT*, Sobol sampler, %d circle obstacles (map_seed 11, radii "
                                     "U(0.3,1.5)) on 100x100, expand_dis 0.5, max_iter %d, %d instances/GPU (seeds 1..)"
@@ -227,7 +245,7 @@ def main():
             "iterations_per_s": iters * ngpu / tmax,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "rppd::rrt_dubins_kernel" if c5 else (
+                         "kernel": "rppr::rrt_rs_kernel" if c6 else "rppd::rrt_dubins_kernel" if c5 else (
                              "rppi::rrt_informed_kernel" if c3 else "rppk2(s)::rrt_star_kernel_v2"),
                          "launches": launches,
                          "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
@@ -245,7 +263,18 @@ def main():
         if not a.no_cpu_baseline and ngpu == 1:   # the CPU baseline is reported by the single-GPU run only
             import oracle
             tc = time.perf_counter()
-            if c5:
+            if c6:
+                kc = dict(max_iter=a.max_iter)
+                ncpu = 64
+                r = None
+                eu = er = 0
+                for sd in range(1, ncpu + 1):
+                    r = oracle.plan_rrt_rs(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], a.max_iter, seed=sd,
+                                           curvature=2.0, robot_radius=0.6, step_size=0.1)
+                    eu += r["stats"]["edges_unique"]
+                    er += r["stats"]["edges_ref"]
+                r["stats"]["edges_unique"], r["stats"]["edges_ref"] = eu, er
+            elif c5:
                 kc = dict(max_iter=min(a.cpu_iters, a.max_iter))
                 r = oracle.plan_dubins(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], kc["max_iter"], seed=1)
             elif c3:

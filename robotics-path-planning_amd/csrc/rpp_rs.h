@@ -182,21 +182,40 @@ RPP_HD static inline bool rs_same(const char* a, const char* b) {
     if (!a[i]) return true;
   }
 }
-// _interpolate :1379-1401
-RPP_HD static inline void rs_interp(double dist, char mode, double maxc, double ox, double oy, double oyaw, double* x,
-                                    double* y, double* yaw) {
+// _interpolate :1379-1401, split so that what is constant along a segment is computed once: (cs, sn) = cos / sin of
+// the segment origin's yaw (straight) or of its negative (arcs); (dx, dy) = the displacement the reference adds
+// to the origin
+RPP_HD static inline void rs_seg_trig(char mode, double oyaw, double* cs, double* sn) {
   if (mode == 'S') {
-    *x = ox + dist / maxc * rpp_glibc_cos(oyaw);
-    *y = oy + dist / maxc * rpp_glibc_sin(oyaw);
-    *yaw = oyaw;
+    *cs = rpp_glibc_cos(oyaw);
+    *sn = rpp_glibc_sin(oyaw);
+  } else {
+    *cs = rpp_glibc_cos(-oyaw);
+    *sn = rpp_glibc_sin(-oyaw);
+  }
+}
+RPP_HD static inline void rs_delta(double dist, char mode, double maxc, double cs, double sn, double* dx, double* dy) {
+  if (mode == 'S') {
+    *dx = dist / maxc * cs;
+    *dy = dist / maxc * sn;
   } else {
     const double ldx = rpp_glibc_sin(dist) / maxc;
     const double ldy = (mode == 'L') ? (1.0 - rpp_glibc_cos(dist)) / maxc : (1.0 - rpp_glibc_cos(dist)) / -maxc;
-    const double c = rpp_glibc_cos(-oyaw), s = rpp_glibc_sin(-oyaw);
-    *x = ox + (c * ldx + s * ldy);
-    *y = oy + (-s * ldx + c * ldy);
-    *yaw = (mode == 'L') ? oyaw + dist : oyaw - dist;
+    *dx = cs * ldx + sn * ldy;
+    *dy = -sn * ldx + cs * ldy;
   }
+}
+RPP_HD static inline double rs_yaw_after(double dist, char mode, double oyaw) {
+  return (mode == 'S') ? oyaw : ((mode == 'L') ? oyaw + dist : oyaw - dist);
+}
+RPP_HD static inline void rs_interp(double dist, char mode, double maxc, double ox, double oy, double oyaw, double* x,
+                                    double* y, double* yaw) {
+  double cs, sn, dx, dy;
+  rs_seg_trig(mode, oyaw, &cs, &sn);
+  rs_delta(dist, mode, maxc, cs, sn, &dx, &dy);
+  *x = ox + dx;
+  *y = oy + dy;
+  *yaw = rs_yaw_after(dist, mode, oyaw);
 }
 // ---- the solver in separable parts (the iteration kernel of rrt_06 runs them cooperatively; rs_plan below is the
 // same sequence on one thread, and is what the known-answer vectors pin) ----------------------------------------
@@ -230,6 +249,12 @@ RPP_HD static inline int rs_variant(int w, int var, const RsFrame& F, double* d,
   if (var >= 2)
     for (int i = 0; ct[i]; i++) ct[i] = (ct[i] == 'L') ? 'R' : (ct[i] == 'R' ? 'L' : 'S');   // reflect
   return 1;
+}
+// the word's letters packed two bits each (equal codes <=> equal ctypes lists)
+RPP_HD static inline uint32_t rs_code(const char* ct) {
+  uint32_t c = 0;
+  for (int i = 0; ct[i]; i++) c |= (uint32_t)(ct[i] == 'L' ? 1 : (ct[i] == 'S' ? 2 : 3)) << (2 * i);
+  return c;
 }
 // set_path :1061-1080 over the variants in the reference's order + `paths.index(min(...))` :1436.
 // st[k], d[k][5], ct[k][6], n[k] for k = 4 * w + var.  Returns the chosen k, -1: None, < -1: the reference raises.
@@ -268,6 +293,7 @@ RPP_HD static inline int rs_select(const int32_t* st, const D5* d, const C6* ct,
 struct RsCourse {
   double len[5], ddist[5];
   double ox[5], oy[5], oyaw[5];
+  double cs[5], sn[5];   // rs_seg_trig of the segment
   int32_t cnt[5];      // arange points of the segment; the segment has cnt + 1 points (np.append(.., length))
   int32_t first[6];    // index of the segment's first point in the polyline
   char ct[6];
@@ -300,11 +326,12 @@ RPP_HD static inline void rs_course(const double* len, const char* ct, int nl, d
     C->cnt[sgm] = (int32_t)cnt;
     C->first[sgm] = tot;
     tot += (int32_t)cnt + 1;
-    double lx, ly, lyaw;
-    rs_interp(length, ct[sgm], maxc, ox, oy, oyaw, &lx, &ly, &lyaw);   // the segment's last point = next origin
-    ox = lx;
-    oy = ly;
-    oyaw = lyaw;
+    double dx, dy;
+    rs_seg_trig(ct[sgm], oyaw, &C->cs[sgm], &C->sn[sgm]);
+    rs_delta(length, ct[sgm], maxc, C->cs[sgm], C->sn[sgm], &dx, &dy);   // the segment's last point = next origin
+    ox = ox + dx;
+    oy = oy + dy;
+    oyaw = rs_yaw_after(length, ct[sgm], oyaw);
   }
   C->ct[nl] = 0;
   C->first[nl] = tot;
@@ -316,8 +343,9 @@ RPP_HD static inline void rs_point(const RsCourse& C, int k, double* wx, double*
   while (sgm + 1 < C.nl && k >= C.first[sgm + 1]) sgm++;
   const int i = k - C.first[sgm];
   const double dist = (i < C.cnt[sgm]) ? 0.0 + (double)i * C.ddist[sgm] : C.len[sgm];
-  double lx, ly, lyaw;
-  rs_interp(dist, C.ct[sgm], C.maxc, C.ox[sgm], C.oy[sgm], C.oyaw[sgm], &lx, &ly, &lyaw);
+  double dx, dy;
+  rs_delta(dist, C.ct[sgm], C.maxc, C.cs[sgm], C.sn[sgm], &dx, &dy);
+  const double lx = C.ox[sgm] + dx, ly = C.oy[sgm] + dy, lyaw = rs_yaw_after(dist, C.ct[sgm], C.oyaw[sgm]);
   *wx = C.cg * lx + C.sg * ly + C.sx;
   *wy = -C.sg * lx + C.cg * ly + C.sy;
   *wyaw = angle_mod_pi(lyaw + C.syaw);

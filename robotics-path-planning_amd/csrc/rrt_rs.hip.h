@@ -11,8 +11,9 @@
 // reference depends on the one before, so the parallelism inside an instance is in the Reeds-Shepp steer:
 //   * the 12 word families x 4 symmetries of generate_path (:1286-1342) are 48 independent closed-form
 //     evaluations: one lane each (rpp::rs_variant);
-//   * set_path's order-dependent filtering and the final arg-min are a short scan over those 48 records: lane 0
-//     (rpp::rs_select), which then lays out the course (segment origins, np.arange counts: rpp::rs_course);
+//   * set_path's order-dependent filtering (:1061-1080) is settled front to back in 48 wave-uniform steps, the
+//     arg-min of :1436 is a wave reduction, and the course is laid out one lane per segment (segment yaws are a
+//     running sum, so each lane knows its own origin yaw; the origins' positions are then a 5-step chain);
 //   * the course's points are independent once the segment origins are known: all lanes generate them
 //     (rpp::rs_point), test them against the LDS obstacle tile as they are produced (:1748-1762) and write them
 //     behind the instance's polyline pool, where they stay if the edge is kept.
@@ -33,18 +34,42 @@ constexpr int TPB = 64;
 constexpr int MAX_OBS = 64;   // obstacle tile in LDS (rrtx_plan refuses larger obstacle sets for this planner)
 constexpr int RS_ST_RAISES = 32;   // include/rrtx.h RRTX_ST_REF_RAISES
 
+#ifdef RRTX_PHASE_TIMERS
+#define RS_T0 int64_t rt_ = (int64_t)__builtin_amdgcn_s_memtime();
+#define RS_T(k) do { if (threadIdx.x == 0) { int64_t t_ = (int64_t)__builtin_amdgcn_s_memtime(); sh.ph[k] += t_ - rt_; rt_ = t_; } } while (0)
+#else
+#define RS_T0
+#define RS_T(k) do { } while (0)
+#endif
+
 struct ShR {
+#ifdef RRTX_PHASE_TIMERS
+  int64_t ph[16];
+#endif
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   double vd[48][5];
   char vct[48][8];
-  int32_t vst[48], vn[48];
+  int32_t vn[48];
+  double sdx[5], sdy[5];      // displacement of each segment's last point from its origin
   rpp::RsCourse course;
   double cost_len;           // sum(|course_lengths|) of the chosen path (:1600)
   double ex, ey, eyaw;       // last point of the course = pose of the node steer() returns (:1592-1594)
   double rx, ry, ryaw;
   int32_t sel, any_hit, flag;
 };
+
+// first minimum of (v, idx) over the wave: lowest v, lowest idx among equals
+__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
+  for (int o = 32; o >= 1; o >>= 1) {
+    const double ov = __shfl_xor(v, o);
+    const int oi = __shfl_xor(idx, o);
+    if (ov < v || (ov == v && oi < idx)) {
+      v = ov;
+      idx = oi;
+    }
+  }
+}
 
 // Cooperative steer (fx,fy,fyaw) -> (tx,ty,tyaw).  Wave-uniform return: 1 a node exists (course in sh.course, its
 // points written at px/py/pyaw when they fit `room`, *coll = check_collision fails, *npts = points), 0 steer
@@ -53,37 +78,113 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
                                     double ty, double tyaw, double* __restrict__ px, double* __restrict__ py,
                                     double* __restrict__ pyaw, int64_t room, int* coll, int* npts) {
   const int lane = threadIdx.x;
+  RS_T0
+  // ---- generate_path :1286-1342: one (word family, symmetry) per lane
+  int st = 0, nn = 0;
+  double L = 0.0;
+  uint32_t code = 0;
   if (lane < 48) {
     rpp::RsFrame F;
     rpp::rs_frame(fx, fy, fyaw, tx, ty, tyaw, da.curvature, da.step_size, &F);
-    int nn = 0;
-    sh.vst[lane] = rpp::rs_variant(lane >> 2, lane & 3, F, sh.vd[lane], sh.vct[lane], &nn);
+    st = rpp::rs_variant(lane >> 2, lane & 3, F, sh.vd[lane], sh.vct[lane], &nn);
+    if (st == 1) {
+      L = rpp::rs_sum_abs(sh.vd[lane], nn);
+      code = rpp::rs_code(sh.vct[lane]);
+    }
     sh.vn[lane] = nn;
+  }
+  RS_T(0);
+  // ---- the reference walks the variants in order and leaves at the first one that raises or reports
+  // "Step size too large" (:1071-1074); nothing before it matters then
+  const unsigned long long term = __ballot(st < 0 || st == 2);
+  if (term) {
+    const int sk = __shfl(st, __ffsll((long long)term) - 1);
+    __syncthreads();
+    return sk < 0 ? sk : 0;
+  }
+  // ---- set_path :1061-1080: variant k is kept unless an EARLIER KEPT one has the same letters and is not longer
+  // by more than step; order-dependent, so the kept ones are settled front to back (48 uniform steps)
+  const double step = da.step_size * da.curvature;
+  const bool cand = (st == 1) && !(L <= step);
+  bool skip = false;
+  for (int i = 0; i < 47; i++) {
+    const unsigned long long km = __ballot(cand && !skip);
+    if (!((km >> i) & 1ULL)) continue;
+    const double Li = __shfl(L, i);
+    const uint32_t ci = __shfl(code, i);
+    if (lane > i && st == 1 && code == ci && (Li - L) <= step) skip = true;
+  }
+  // paths.index(min(paths, key=abs(L))) :1436 -- first minimum
+  const bool kept = cand && !skip;
+  double bv = kept ? rpp::dabs(L / da.curvature) : rpp::dinf();
+  int sel = kept ? lane : 0x7fffffff;
+  wave_argmin(bv, sel);
+  RS_T(1);
+  __syncthreads();
+  if (sel == 0x7fffffff) return 0;   // no path: steer returns None
+  // ---- generate_local_course :1355-1377 laid out for random access: one lane per segment, then a short chain
+  const int nl = sh.vn[sel];
+  rpp::RsCourse& C = sh.course;
+  if (lane < nl) {
+    double oyaw = 0.0;
+    for (int q = 0; q < lane; q++) oyaw = rpp::rs_yaw_after(sh.vd[sel][q], sh.vct[sel][q], oyaw);
+    const double len = sh.vd[sel][lane];
+    const char md = sh.vct[sel][lane];
+    const double ds = da.step_size * da.curvature;
+    const double d_dist = len >= 0.0 ? ds : -ds;
+    const double q = (len - 0.0) / d_dist;            // np.arange(0.0, length, d_dist)
+    const long cnt = (q > 0.0) ? (long)__builtin_ceil(q) : 0;
+    double cs, sn, dx, dy;
+    rpp::rs_seg_trig(md, oyaw, &cs, &sn);
+    rpp::rs_delta(len, md, da.curvature, cs, sn, &dx, &dy);
+    C.len[lane] = len;
+    C.ddist[lane] = d_dist;
+    C.ct[lane] = md;
+    C.oyaw[lane] = oyaw;
+    C.cs[lane] = cs;
+    C.sn[lane] = sn;
+    C.cnt[lane] = (int32_t)cnt;
+    sh.sdx[lane] = dx;
+    sh.sdy[lane] = dy;
+  } else if (lane == 8) {
+    C.cg = rpp_glibc_cos(-fyaw);
+    C.sg = rpp_glibc_sin(-fyaw);
+    C.sx = fx;
+    C.sy = fy;
+    C.syaw = fyaw;
+    C.maxc = da.curvature;
+    double s = 0.0;
+    for (int i = 0; i < nl; i++) s += rpp::dabs(sh.vd[sel][i] / da.curvature);
+    sh.cost_len = s;
   }
   __syncthreads();
   if (lane == 0) {
-    const int sel = rpp::rs_select(sh.vst, sh.vd, sh.vct, sh.vn, da.step_size * da.curvature, da.curvature);
-    sh.sel = sel;
-    sh.any_hit = 0;
-    if (sel >= 0) {
-      rpp::rs_course(sh.vd[sel], sh.vct[sel], sh.vn[sel], fx, fy, fyaw, da.curvature, da.step_size, &sh.course);
-      double s = 0.0;
-      for (int i = 0; i < sh.vn[sel]; i++) s += rpp::dabs(sh.vd[sel][i] / da.curvature);
-      sh.cost_len = s;
+    double ox = 0.0, oy = 0.0;
+    int tot = 0;
+    for (int sgm = 0; sgm < nl; sgm++) {
+      C.ox[sgm] = ox;
+      C.oy[sgm] = oy;
+      C.first[sgm] = tot;
+      tot += C.cnt[sgm] + 1;
+      ox = ox + sh.sdx[sgm];
+      oy = oy + sh.sdy[sgm];
     }
+    C.ct[nl] = 0;
+    C.first[nl] = tot;
+    C.total = tot;
+    C.nl = nl;
+    sh.any_hit = 0;
   }
   __syncthreads();
-  const int sel = sh.sel;
-  if (sel < -1) return sel;
-  if (sel < 0) return 0;
-  const int total = sh.course.total;
+  RS_T(2);
+  const int total = C.total;
   *npts = total;
   if (total <= 0) return 0;   // `if not px` :1588
   if (total > room) return -1;
   int hit = 0;
   for (int k = lane; k < total; k += TPB) {
     double wx, wy, wyaw;
-    rpp::rs_point(sh.course, k, &wx, &wy, &wyaw);
+    rpp::rs_point(C, k, &wx, &wy, &wyaw);
     px[k] = wx;
     py[k] = wy;
     pyaw[k] = wyaw;
@@ -99,20 +200,9 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
   }
   if (hit) sh.any_hit = 1;
   __syncthreads();
+  RS_T(3);
   *coll = sh.any_hit;
   return 1;
-}
-
-// first minimum of (v, idx) over the wave: lowest v, lowest idx among equals
-__device__ __forceinline__ void wave_argmin(double& v, int& idx) {
-  for (int o = 32; o >= 1; o >>= 1) {
-    const double ov = __shfl_xor(v, o);
-    const int oi = __shfl_xor(idx, o);
-    if (ov < v || (ov == v && oi < idx)) {
-      v = ov;
-      idx = oi;
-    }
-  }
 }
 
 __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iters) {
@@ -144,6 +234,10 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
     sh.othr[i] = c.othr[i];
   }
   if (lane == 0) sh.rng.pos = I->rng.pos;
+#ifdef RRTX_PHASE_TIMERS
+  if (lane < 16) sh.ph[lane] = 0;
+  const int64_t tk0_ = (int64_t)__builtin_amdgcn_s_memtime();
+#endif
   __syncthreads();
   int n = I->n, it = I->it;
   int64_t pool_used = da.pool_used[inst];
@@ -154,7 +248,7 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
     plen[0] = 0;
   }
   __syncthreads();
-  int64_t s_iter = 0, s_e = 0, s_nh = 0, s_rw = 0, s_pr = 0, s_sn = 0;
+  int64_t s_iter = 0, s_e = 0, s_nh = 0, s_rw = 0, s_pr = 0, s_sn = 0, s_pts = 0;
   int stop = 0, done_early = 0, raised = 0;
 
   // search_best_goal_node :1815-1836: lowest cost inside both thresholds, first index among equals
@@ -230,7 +324,8 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
     const int ok0 = rs_edge(da, m, sh, x[ni], y[ni], yaw[ni], rx, ry, ryaw, pool_x + pool_used, pool_y + pool_used,
                             pool_w + pool_used, da.pool_cap - pool_used, &coll, &np0);
     if (fatal(ok0)) break;
-    s_e++;
+    s_e += ok0 ? 1 : 0;   // collision-checked edges (check_collision calls on a node), as the oracle counts them
+    s_pts += ok0 ? np0 : 0;
     int nnear = -1;
     int truthy = ok0;   // `new_node` as the early-return test :1557 sees it
     if (ok0 && !coll) {
@@ -282,7 +377,8 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
         const int tk = rs_edge(da, m, sh, x[i], y[i], yaw[i], nx, ny, nyaw, pool_x + pool_used, pool_y + pool_used,
                                pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);
         if (fatal(tk)) break;
-        s_e++;
+        s_e += tk ? 1 : 0;
+        s_pts += tk ? npt : 0;
         if (tk && !cl) {
           const double cc = cost[i] + rpp::py_hypot(nx - x[i], ny - y[i]);   // Euclidean :1901-1903
           if (cc < min_cost) {
@@ -302,7 +398,7 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
         const int bk = rs_edge(da, m, sh, x[min_ind], y[min_ind], yaw[min_ind], nx, ny, nyaw, pool_x + pool_used,
                                pool_y + pool_used, pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);   // :1810
         if (fatal(bk)) break;
-        s_e++;
+        s_pts += bk ? npt : 0;   // the re-steer of :1810 is not collision-checked again
         const int me = n;
         append_node(min_ind, min_cost, npt);                                  // :1811, :1548
         // ---------------- rewire :1865-1899
@@ -312,7 +408,8 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
           const int ek = rs_edge(da, m, sh, x[me], y[me], yaw[me], x[i], y[i], yaw[i], pool_x + pool_used,
                                  pool_y + pool_used, pool_w + pool_used, da.pool_cap - pool_used, &rc2, &rn);
           if (fatal(ek)) break;
-          s_e++;
+          s_e += ek ? 1 : 0;
+          s_pts += ek ? rn : 0;
           if (!ek) continue;
           const double ec = cost[me] + rpp::py_hypot(x[i] - x[me], y[i] - y[me]);
           if (!rc2 && cost[i] > ec) {
@@ -361,7 +458,8 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
         const int gk = rs_edge(da, m, sh, x[me], y[me], yaw[me], gx, gy, da.goal_yaw, pool_x + pool_used,
                                pool_y + pool_used, pool_w + pool_used, da.pool_cap - pool_used, &gc, &gn);
         if (fatal(gk)) break;
-        s_e++;
+        s_e += gk ? 1 : 0;
+        s_pts += gk ? gn : 0;
         if (gk && !gc) append_node(me, cost[me] + sh.cost_len, gn);
       }
     }
@@ -418,8 +516,15 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
     I->rewires += s_rw;
     I->propagated += s_pr;
     I->scan_nodes += s_sn;
+    // algorithmic bytes: 16 B per node and scan (x, y), 24 B per polyline point produced (x, y, yaw written once)
+    I->alg_bytes += 16 * s_sn + 24 * s_pts;
+    I->alg_bytes2 += 16 * s_sn + 24 * s_pts;
     c.results[inst].n_nodes = n;
     c.results[inst].status = I->status;
+#ifdef RRTX_PHASE_TIMERS
+    for (int k = 0; k < 4; k++) I->phase[k] += sh.ph[k];   // 0 variants, 1 select, 2 course, 3 points
+    I->phase[15] += (int64_t)__builtin_amdgcn_s_memtime() - tk0_;   // whole kernel
+#endif
   }
 }
 

@@ -334,7 +334,7 @@ def _orc06(a):
                            curvature=float(g["curvature"]), robot_radius=float(g["robot_radius"]),
                            expand_dis=float(g["expand_dis"]), connect_circle_dist=float(g["connect_circle_dist"]),
                            step_size=float(g["step_size"]))
-    return r["x"], r["y"], r["cost"], r["parent"], r["yaw"], r["poly_x"], r["path"], r["path_yaw"]
+    return r["x"], r["y"], r["cost"], r["parent"], r["yaw"], r["poly_x"], r["path"], r["path_yaw"], r["stats"]
 
 
 def test_gpu_reeds_shepp_many_seeds_equal_oracle(gpu):
@@ -356,6 +356,9 @@ def test_gpu_reeds_shepp_many_seeds_equal_oracle(gpu):
             found += 1
             assert np.array_equal(out["paths"][i], r[6]) and np.array_equal(out["path_yaws"][i], r[7])
     assert found > 48
+    # the bench's unit of work means the same thing on both sides: collision-checked edges, rewires
+    assert out["stats"]["edges_unique"] == sum(r[8]["edges_unique"] for r in refs)
+    assert out["stats"]["rewires"] == sum(r[8]["rewires"] for r in refs)
 
 
 def test_reeds_shepp_host_class_drop_in(gpu):
