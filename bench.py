@@ -44,7 +44,7 @@ def main():
                          "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 1024 instances; "
                          "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1536 instances; "
                          "c4: rrt_08 BIT*, driver constants, per-instance start/goal (SURVEY 8d), 80 iterations; "
-                         "c6: rrt_06 RRT*-Reeds-Shepp, driver constants, 750 iterations / 4096 instances")
+                         "c6: rrt_06 RRT*-Reeds-Shepp, driver constants, 750 iterations / 16384 instances")
     ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
@@ -66,7 +66,7 @@ def main():
         if "--max-iter" not in sys.argv:
             a.max_iter = 750
         if "--instances" not in sys.argv:
-            a.instances = 4096      # two rounds of 8 waves per CU
+            a.instances = 16384     # four rounds of 16 waves per CU
         a.warmup_max_iter = 0
     if c5 and not c6:
         if "--max-iter" not in sys.argv:

@@ -41,132 +41,119 @@ RPP_HD static inline void rs_ct(char* ct, const char* w) {
   for (; w[i]; i++) ct[i] = w[i];
   ct[i] = 0;
 }
-// one word family (:1088-1269): 1 = found (d, ct, n filled); *err set where the reference raises
+// one word family (:1088-1269): 1 = found (d, ct, n filled); *err set where the reference raises.
+// Written as ONE code path with per-family operands instead of twelve separate bodies: on the device the twelve
+// families of a steer sit in different lanes of the same wave, and every libm-grade call (pow, atan2, acos, sin,
+// asin, the three mod2pi) is then executed once for all of them instead of once per family.  Each family still
+// evaluates exactly the expressions of its reference function, in the reference's order:
+//   0 left_straight_left :1088        1 left_straight_right :1100     2 left_x_right_x_left :1114
+//   3 left_x_right_left :1127         4 left_right_x_left :1140       5 left_right_x_left_right :1154
+//   6 left_x_right_left_x_right :1170 7 left_x_right90_straight_left :1189
+//   8 left_x_right90_straight_right :1205   9 left_straight_right90_x_left :1218
+//   10 left_straight_left90_x_right :1234   11 left_x_right90_straight_left90_x_right :1247
 RPP_HD static inline int rs_word(int w, double x, double y, double phi, double* d, char* ct, int* n, int* err) {
+  const double hp = kPi / 2;
   const double sp = rpp_glibc_sin(phi), cp = rpp_glibc_cos(phi);
   const bool plus = (w == 1 || w == 5 || w == 6 || w == 8 || w == 10 || w == 11);   // words built on (x + sin, y - 1 - cos)
   const double zeta = plus ? x + sp : x - sp;
   const double eeta = plus ? y - 1.0 - cp : y - 1.0 + cp;
-  double u1 = py_hypot(zeta, eeta);
+  const double u1 = py_hypot(zeta, eeta);
   const double theta = rpp_glibc_atan2(eeta, zeta);
-  double u, t, v, A;
+  const bool need_sq = (w == 1 || w == 4 || w == 6 || w == 7 || w == 9 || w == 11);
+  const double u1sq = need_sq ? py_sq(u1) : 0.0;
+  const double u2 = (20 - u1sq) / 16;   // family 6
+  bool live;
+  if (w == 0) live = (0.0 <= theta && theta <= kPi);
+  else if (w == 1) live = u1sq >= 4.0;
+  else if (w <= 4) live = u1 <= 4.0;
+  else if (w == 5) live = u1 <= 2;
+  else if (w == 6) live = (0 <= u2 && u2 <= 1);
+  else if (w <= 10) live = u1 >= 2.0;
+  else live = u1 >= 4.0;
+  if (!live) return 0;
+  // sqrt(u1 ** 2 - 4) and the atan2 built on it (families 1, 7, 9, 11)
+  const bool need_r = (w == 1 || w == 7 || w == 9 || w == 11);
+  const double r = need_r ? __builtin_sqrt(u1sq - 4.0) : 0.0;
+  double A = 0.0;
+  if (need_r) A = rpp_glibc_atan2(w == 9 ? r : 2.0, w == 9 ? 2.0 : r);
+  // acos (families 2 .. 6)
+  double AC = 0.0;
+  if (w >= 2 && w <= 6) {
+    const double arg = (w <= 3) ? 0.25 * u1 : (w == 4 ? 1 - u1sq * 0.125 : (w == 5 ? (u1 + 2) * 0.25 : u2));
+    AC = rpp_glibc_acos(arg);
+  }
+  // asin(2 sin(u) / u1) (families 4, 6)
+  double A2 = 0.0;
+  if (w == 4 || w == 6) {
+    const double num = 2 * rpp_glibc_sin(AC);
+    if (u1 == 0.0) { *err = -3; return 0; }
+    const double q = num / u1;
+    if (!(dabs(q) <= 1.0)) { *err = -4; return 0; }
+    A2 = rpp_glibc_asin(q);
+  }
+  // t
+  double targ;
   switch (w) {
-    case 0:   // left_straight_left
-      if (0.0 <= theta && theta <= kPi) {
-        v = rs_mod2pi(phi - theta);
-        if (0.0 <= v && v <= kPi) { d[0] = theta; d[1] = u1; d[2] = v; rs_ct(ct, "LSL"); *n = 3; return 1; }
-      }
+    case 0: targ = 0.0; break;
+    case 1: targ = theta + A; break;
+    case 2: case 3: targ = AC + theta + hp; break;
+    case 4: targ = -A2 + theta + hp; break;
+    case 5: targ = theta + AC + hp; break;
+    case 6: targ = theta + A2 + hp; break;
+    case 7: case 11: targ = theta + A + hp; break;
+    case 8: targ = theta + hp; break;
+    case 9: targ = theta - A + hp; break;
+    default: targ = theta; break;   // 10
+  }
+  const double t = (w == 0) ? theta : rs_mod2pi(targ);
+  // u where it is an angle of its own (families 2, 3, 5)
+  double u = 0.0;
+  if (w == 2 || w == 3 || w == 5) u = rs_mod2pi(w == 5 ? AC : kPi - 2 * AC);
+  // v
+  double varg;
+  switch (w) {
+    case 0: varg = phi - theta; break;
+    case 1: case 6: case 11: varg = t - phi; break;
+    case 2: varg = phi - t - u; break;
+    case 3: varg = -phi + t + u; break;
+    case 4: varg = t - AC - phi; break;
+    case 5: varg = phi - t + 2 * u; break;
+    case 7: varg = t - phi + hp; break;
+    case 9: varg = t - phi - hp; break;
+    default: varg = phi - t - hp; break;   // 8, 10
+  }
+  const double v = rs_mod2pi(varg);
+  switch (w) {
+    case 0:
+      if (0.0 <= v && v <= kPi) { d[0] = theta; d[1] = u1; d[2] = v; rs_ct(ct, "LSL"); *n = 3; return 1; }
       return 0;
-    case 1:   // left_straight_right
-      u1 = py_sq(u1);
-      if (u1 >= 4.0) {
-        u = __builtin_sqrt(u1 - 4.0);
-        t = rs_mod2pi(theta + rpp_glibc_atan2(2.0, u));
-        v = rs_mod2pi(t - phi);
-        if (t >= 0.0 && v >= 0.0) { d[0] = t; d[1] = u; d[2] = v; rs_ct(ct, "LSR"); *n = 3; return 1; }
-      }
+    case 1:
+      if (t >= 0.0 && v >= 0.0) { d[0] = t; d[1] = r; d[2] = v; rs_ct(ct, "LSR"); *n = 3; return 1; }
       return 0;
-    case 2:   // left_x_right_x_left
-      if (u1 <= 4.0) {
-        A = rpp_glibc_acos(0.25 * u1);
-        t = rs_mod2pi(A + theta + kPi / 2);
-        u = rs_mod2pi(kPi - 2 * A);
-        v = rs_mod2pi(phi - t - u);
-        d[0] = t; d[1] = -u; d[2] = v; rs_ct(ct, "LRL"); *n = 3; return 1;
-      }
+    case 2: d[0] = t; d[1] = -u; d[2] = v; rs_ct(ct, "LRL"); *n = 3; return 1;
+    case 3: d[0] = t; d[1] = -u; d[2] = -v; rs_ct(ct, "LRL"); *n = 3; return 1;
+    case 4: d[0] = t; d[1] = AC; d[2] = -v; rs_ct(ct, "LRL"); *n = 3; return 1;
+    case 5:
+      if (t >= 0 && u >= 0 && v >= 0) { d[0] = t; d[1] = u; d[2] = -u; d[3] = -v; rs_ct(ct, "LRLR"); *n = 4; return 1; }
       return 0;
-    case 3:   // left_x_right_left
-      if (u1 <= 4.0) {
-        A = rpp_glibc_acos(0.25 * u1);
-        t = rs_mod2pi(A + theta + kPi / 2);
-        u = rs_mod2pi(kPi - 2 * A);
-        v = rs_mod2pi(-phi + t + u);
-        d[0] = t; d[1] = -u; d[2] = -v; rs_ct(ct, "LRL"); *n = 3; return 1;
-      }
+    case 6:
+      if (t >= 0 && v >= 0) { d[0] = t; d[1] = -AC; d[2] = -AC; d[3] = v; rs_ct(ct, "LRLR"); *n = 4; return 1; }
       return 0;
-    case 4:   // left_right_x_left
-      if (u1 <= 4.0) {
-        u = rpp_glibc_acos(1 - py_sq(u1) * 0.125);
-        const double num = 2 * rpp_glibc_sin(u);
-        if (u1 == 0.0) { *err = -3; return 0; }
-        const double q = num / u1;
-        if (!(dabs(q) <= 1.0)) { *err = -4; return 0; }
-        A = rpp_glibc_asin(q);
-        t = rs_mod2pi(-A + theta + kPi / 2);
-        v = rs_mod2pi(t - u - phi);
-        d[0] = t; d[1] = u; d[2] = -v; rs_ct(ct, "LRL"); *n = 3; return 1;
-      }
+    case 7:
+      if (t >= 0 && v >= 0) { d[0] = t; d[1] = -hp; d[2] = -(r - 2); d[3] = -v; rs_ct(ct, "LRSL"); *n = 4; return 1; }
       return 0;
-    case 5:   // left_right_x_left_right
-      if (u1 <= 2) {
-        A = rpp_glibc_acos((u1 + 2) * 0.25);
-        t = rs_mod2pi(theta + A + kPi / 2);
-        u = rs_mod2pi(A);
-        v = rs_mod2pi(phi - t + 2 * u);
-        if (t >= 0 && u >= 0 && v >= 0) { d[0] = t; d[1] = u; d[2] = -u; d[3] = -v; rs_ct(ct, "LRLR"); *n = 4; return 1; }
-      }
+    case 8:
+      if (t >= 0 && v >= 0) { d[0] = t; d[1] = -hp; d[2] = -(u1 - 2); d[3] = -v; rs_ct(ct, "LRSR"); *n = 4; return 1; }
       return 0;
-    case 6: {   // left_x_right_left_x_right
-      const double u2 = (20 - py_sq(u1)) / 16;
-      if (0 <= u2 && u2 <= 1) {
-        u = rpp_glibc_acos(u2);
-        const double num = 2 * rpp_glibc_sin(u);
-        if (u1 == 0.0) { *err = -3; return 0; }
-        const double q = num / u1;
-        if (!(dabs(q) <= 1.0)) { *err = -4; return 0; }
-        A = rpp_glibc_asin(q);
-        t = rs_mod2pi(theta + A + kPi / 2);
-        v = rs_mod2pi(t - phi);
-        if (t >= 0 && v >= 0) { d[0] = t; d[1] = -u; d[2] = -u; d[3] = v; rs_ct(ct, "LRLR"); *n = 4; return 1; }
-      }
+    case 9:
+      if (t >= 0 && v >= 0) { d[0] = t; d[1] = r - 2; d[2] = hp; d[3] = -v; rs_ct(ct, "LSRL"); *n = 4; return 1; }
       return 0;
-    }
-    case 7:   // left_x_right90_straight_left
-      if (u1 >= 2.0) {
-        const double r = __builtin_sqrt(py_sq(u1) - 4);
-        u = r - 2;
-        A = rpp_glibc_atan2(2.0, r);
-        t = rs_mod2pi(theta + A + kPi / 2);
-        v = rs_mod2pi(t - phi + kPi / 2);
-        if (t >= 0 && v >= 0) { d[0] = t; d[1] = -kPi / 2; d[2] = -u; d[3] = -v; rs_ct(ct, "LRSL"); *n = 4; return 1; }
-      }
+    case 10:
+      if (t >= 0 && v >= 0) { d[0] = t; d[1] = u1 - 2; d[2] = hp; d[3] = -v; rs_ct(ct, "LSLR"); *n = 4; return 1; }
       return 0;
-    case 8:   // left_x_right90_straight_right
-      if (u1 >= 2.0) {
-        t = rs_mod2pi(theta + kPi / 2);
-        u = u1 - 2;
-        v = rs_mod2pi(phi - t - kPi / 2);
-        if (t >= 0 && v >= 0) { d[0] = t; d[1] = -kPi / 2; d[2] = -u; d[3] = -v; rs_ct(ct, "LRSR"); *n = 4; return 1; }
-      }
-      return 0;
-    case 9:   // left_straight_right90_x_left
-      if (u1 >= 2.0) {
-        const double r = __builtin_sqrt(py_sq(u1) - 4);
-        u = r - 2;
-        A = rpp_glibc_atan2(r, 2.0);
-        t = rs_mod2pi(theta - A + kPi / 2);
-        v = rs_mod2pi(t - phi - kPi / 2);
-        if (t >= 0 && v >= 0) { d[0] = t; d[1] = u; d[2] = kPi / 2; d[3] = -v; rs_ct(ct, "LSRL"); *n = 4; return 1; }
-      }
-      return 0;
-    case 10:   // left_straight_left90_x_right
-      if (u1 >= 2.0) {
-        t = rs_mod2pi(theta);
-        u = u1 - 2;
-        v = rs_mod2pi(phi - t - kPi / 2);
-        if (t >= 0 && v >= 0) { d[0] = t; d[1] = u; d[2] = kPi / 2; d[3] = -v; rs_ct(ct, "LSLR"); *n = 4; return 1; }
-      }
-      return 0;
-    default:   // left_x_right90_straight_left90_x_right
-      if (u1 >= 4.0) {
-        const double r = __builtin_sqrt(py_sq(u1) - 4);
-        u = r - 4;
-        A = rpp_glibc_atan2(2.0, r);
-        t = rs_mod2pi(theta + A + kPi / 2);
-        v = rs_mod2pi(t - phi);
-        if (t >= 0 && v >= 0) {
-          d[0] = t; d[1] = -kPi / 2; d[2] = -u; d[3] = -kPi / 2; d[4] = v; rs_ct(ct, "LRSLR"); *n = 5; return 1;
-        }
+    default:
+      if (t >= 0 && v >= 0) {
+        d[0] = t; d[1] = -hp; d[2] = -(r - 4); d[3] = -hp; d[4] = v; rs_ct(ct, "LRSLR"); *n = 5; return 1;
       }
       return 0;
   }
@@ -185,14 +172,12 @@ RPP_HD static inline bool rs_same(const char* a, const char* b) {
 // _interpolate :1379-1401, split so that what is constant along a segment is computed once: (cs, sn) = cos / sin of
 // the segment origin's yaw (straight) or of its negative (arcs); (dx, dy) = the displacement the reference adds
 // to the origin
+// (the arcs' cos(-yaw), sin(-yaw) are taken as cos(yaw), -sin(yaw): the replicas are even / odd bit for bit, which
+// tests/native/core_host_check.cpp pins; one code path for straight and arc lanes on the device)
 RPP_HD static inline void rs_seg_trig(char mode, double oyaw, double* cs, double* sn) {
-  if (mode == 'S') {
-    *cs = rpp_glibc_cos(oyaw);
-    *sn = rpp_glibc_sin(oyaw);
-  } else {
-    *cs = rpp_glibc_cos(-oyaw);
-    *sn = rpp_glibc_sin(-oyaw);
-  }
+  const double c0 = rpp_glibc_cos(oyaw), s0 = rpp_glibc_sin(oyaw);
+  *cs = c0;
+  *sn = (mode == 'S') ? s0 : -s0;
 }
 RPP_HD static inline void rs_delta(double dist, char mode, double maxc, double cs, double sn, double* dx, double* dy) {
   if (mode == 'S') {
@@ -222,6 +207,7 @@ RPP_HD static inline void rs_interp(double dist, char mode, double maxc, double 
 // local frame of generate_path :1286-1296
 struct RsFrame {
   double x, y, dth, step;
+  double c, s;   // cos / sin of the start yaw
 };
 RPP_HD static inline void rs_frame(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
                                    double step_size, RsFrame* F) {
@@ -230,6 +216,8 @@ RPP_HD static inline void rs_frame(double sx, double sy, double syaw, double gx,
   const double c = rpp_glibc_cos(syaw), s = rpp_glibc_sin(syaw);
   F->x = (c * dx + s * dy) * maxc;
   F->y = (-s * dx + c * dy) * maxc;
+  F->c = c;
+  F->s = s;
   F->step = step_size * maxc;
 }
 // One (word family w, symmetry var) of generate_path :1298-1340.  Returns 0: no path from this variant, 1: a path

@@ -83,8 +83,9 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
   int st = 0, nn = 0;
   double L = 0.0;
   uint32_t code = 0;
+  rpp::RsFrame F;
+  F.c = F.s = 0.0;
   if (lane < 48) {
-    rpp::RsFrame F;
     rpp::rs_frame(fx, fy, fyaw, tx, ty, tyaw, da.curvature, da.step_size, &F);
     st = rpp::rs_variant(lane >> 2, lane & 3, F, sh.vd[lane], sh.vct[lane], &nn);
     if (st == 1) {
@@ -107,9 +108,10 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
   const double step = da.step_size * da.curvature;
   const bool cand = (st == 1) && !(L <= step);
   bool skip = false;
-  for (int i = 0; i < 47; i++) {
-    const unsigned long long km = __ballot(cand && !skip);
-    if (!((km >> i) & 1ULL)) continue;
+  for (int i = -1;;) {
+    const unsigned long long km = __ballot(cand && !skip) & (i < 0 ? ~0ULL : ~((2ULL << i) - 1ULL));   // still kept, behind i
+    if (!km) break;
+    i = __ffsll((long long)km) - 1;
     const double Li = __shfl(L, i);
     const uint32_t ci = __shfl(code, i);
     if (lane > i && st == 1 && code == ci && (Li - L) <= step) skip = true;
@@ -147,8 +149,8 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
     sh.sdx[lane] = dx;
     sh.sdy[lane] = dy;
   } else if (lane == 8) {
-    C.cg = rpp_glibc_cos(-fyaw);
-    C.sg = rpp_glibc_sin(-fyaw);
+    C.cg = F.c;     // cos(-syaw), sin(-syaw) of :1411-1417 from the frame's cos / sin(syaw) (even / odd bit for bit)
+    C.sg = -F.s;
     C.sx = fx;
     C.sy = fy;
     C.syaw = fyaw;
@@ -205,7 +207,10 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
   return 1;
 }
 
-__global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iters) {
+#ifndef RS_WAVES
+#define RS_WAVES 4   // measured: 2 waves/SIMD (no spills) 3.3, 4 waves 5.8, 6 waves 6.5 plans/ms on the c6 workload
+#endif
+__global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, RS_WAVES))) void rrt_rs_kernel(Ctx c, DubArgs da, int iters) {
   __shared__ ShR sh;
   const int inst = blockIdx.x;
   const int lane = threadIdx.x;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
     plen[0] = 0;
   }
   __syncthreads();
-  int64_t s_iter = 0, s_e = 0, s_nh = 0, s_rw = 0, s_pr = 0, s_sn = 0, s_pts = 0;
+  int64_t s_iter = 0, s_e = 0, s_nh = 0, s_rw = 0, s_pr = 0, s_sn = 0, s_pts = 0, s_ref = 0;
   int stop = 0, done_early = 0, raised = 0;
 
   // search_best_goal_node :1815-1836: lowest cost inside both thresholds, first index among equals
@@ -369,22 +374,63 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
         __syncthreads();
       }
       // ---------------- choose_parent :1772-1813
+      // The reference steers from EVERY near node and keeps the cheapest collision-free one (first in list order
+      // among equal costs).  The cost of a candidate (:1901: parent cost + Euclidean distance) does not depend on
+      // its steer, so the candidates are tried in ascending (cost, list position) order and the first one whose
+      // edge exists and is collision free IS that minimum; the others are never steered (da.eager = 1 steers all
+      // of them like the reference: same result, and RRTX_ST_REF_RAISES then also covers the edges skipped here).
       double min_cost = rpp::dinf();
-      int min_ind = -1;
-      for (int p = 0; p < k; p++) {
-        const int i = near[p];
-        int cl = 0, npt = 0;
-        const int tk = rs_edge(da, m, sh, x[i], y[i], yaw[i], nx, ny, nyaw, pool_x + pool_used, pool_y + pool_used,
-                               pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);
-        if (fatal(tk)) break;
-        s_e += tk ? 1 : 0;
-        s_pts += tk ? npt : 0;
-        if (tk && !cl) {
-          const double cc = cost[i] + rpp::py_hypot(nx - x[i], ny - y[i]);   // Euclidean :1901-1903
-          if (cc < min_cost) {
-            min_cost = cc;
-            min_ind = i;
+      int min_ind = -1, npt = 0;
+      s_ref += k;
+      if (da.eager) {
+        for (int p = 0; p < k; p++) {
+          const int i = near[p];
+          int cl = 0;
+          const int tk = rs_edge(da, m, sh, x[i], y[i], yaw[i], nx, ny, nyaw, pool_x + pool_used, pool_y + pool_used,
+                                 pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);
+          if (fatal(tk)) break;
+          s_e += tk ? 1 : 0;
+          s_pts += tk ? npt : 0;
+          if (tk && !cl) {
+            const double cc = cost[i] + rpp::py_hypot(nx - x[i], ny - y[i]);   // Euclidean :1901-1903
+            if (cc < min_cost) {
+              min_cost = cc;
+              min_ind = i;
+            }
           }
+        }
+      } else {
+        for (int p = lane; p < k; p += TPB) {
+          const int i = near[p];
+          ndist[p] = cost[i] + rpp::py_hypot(nx - x[i], ny - y[i]);
+        }
+        __syncthreads();
+        for (;;) {
+          double bv = rpp::dinf();
+          int bp = 0x7fffffff;
+          for (int p = lane; p < k; p += TPB) {
+            const double v = ndist[p];
+            if (v < bv) {
+              bv = v;
+              bp = p;
+            }
+          }
+          wave_argmin(bv, bp);
+          if (bp == 0x7fffffff) break;   // every candidate tried: "There is no good path" :1805
+          const int i = near[bp];
+          int cl = 0;
+          const int tk = rs_edge(da, m, sh, x[i], y[i], yaw[i], nx, ny, nyaw, pool_x + pool_used, pool_y + pool_used,
+                                 pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);
+          if (fatal(tk)) break;
+          s_e += tk ? 1 : 0;
+          s_pts += tk ? npt : 0;
+          if (tk && !cl) {
+            min_cost = bv;
+            min_ind = i;
+            break;
+          }
+          if (lane == 0) ndist[bp] = rpp::dinf();
+          __syncthreads();
         }
       }
       if (stop) break;
@@ -394,15 +440,42 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
           stop = 1;
           break;
         }
-        int cl = 0, npt = 0;
-        const int bk = rs_edge(da, m, sh, x[min_ind], y[min_ind], yaw[min_ind], nx, ny, nyaw, pool_x + pool_used,
-                               pool_y + pool_used, pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);   // :1810
-        if (fatal(bk)) break;
-        s_pts += bk ? npt : 0;   // the re-steer of :1810 is not collision-checked again
+        if (da.eager) {
+          // the re-steer of :1810 (not collision-checked again); in the lazy order the winner is the edge just laid out
+          int cl = 0;
+          const int bk = rs_edge(da, m, sh, x[min_ind], y[min_ind], yaw[min_ind], nx, ny, nyaw, pool_x + pool_used,
+                                 pool_y + pool_used, pool_w + pool_used, da.pool_cap - pool_used, &cl, &npt);
+          if (fatal(bk)) break;
+          s_pts += bk ? npt : 0;
+        }
         const int me = n;
         append_node(min_ind, min_cost, npt);                                  // :1811, :1548
         // ---------------- rewire :1865-1899
+        // (lazy order: an edge new -> near is only steered when `improved_cost` :1888 holds at the moment of the
+        // visit; a missing or colliding edge changes nothing, :1877-1878 / :1890)
+        s_ref += k;
         for (int p = 0; p < k; p++) {
+          if (!da.eager) {
+            // next list position whose node would get cheaper; costs are re-read after every rewire
+            int q = p;
+            for (;;) {
+              const int pp = q + lane;
+              bool f = false;
+              if (pp < k) {
+                const int i2 = near[pp];
+                f = cost[i2] > cost[me] + rpp::py_hypot(x[i2] - x[me], y[i2] - y[me]);
+              }
+              const unsigned long long fm = __ballot(f);
+              if (fm) {
+                q += __ffsll((long long)fm) - 1;
+                break;
+              }
+              q += TPB;
+              if (q >= k) break;
+            }
+            p = q;
+            if (p >= k) break;
+          }
           const int i = near[p];
           int rc2 = 0, rn = 0;
           const int ek = rs_edge(da, m, sh, x[me], y[me], yaw[me], x[i], y[i], yaw[i], pool_x + pool_used,
@@ -510,7 +583,7 @@ __global__ __launch_bounds__(TPB) void rrt_rs_kernel(Ctx c, DubArgs da, int iter
     }
     I->iterations += s_iter;
     I->edges_unique += s_e;
-    I->edges_ref += s_e;
+    I->edges_ref += da.eager ? s_e : s_ref + 2 * s_iter;   // lazy order: candidates the reference would have steered (upper bound)
     I->near_hits += s_nh;
     I->near_unique += s_nh;
     I->rewires += s_rw;

@@ -356,9 +356,21 @@ def test_gpu_reeds_shepp_many_seeds_equal_oracle(gpu):
             found += 1
             assert np.array_equal(out["paths"][i], r[6]) and np.array_equal(out["path_yaws"][i], r[7])
     assert found > 48
-    # the bench's unit of work means the same thing on both sides: collision-checked edges, rewires
-    assert out["stats"]["edges_unique"] == sum(r[8]["edges_unique"] for r in refs)
     assert out["stats"]["rewires"] == sum(r[8]["rewires"] for r in refs)
+    # default = lazy candidate order (only edges that can change the result are steered); RRTX_RS_EAGER=1 steers every
+    # choose_parent / rewire candidate like the reference: same trees, and then the unit of work (collision-checked
+    # edges) is the oracle's count exactly
+    assert out["stats"]["edges_unique"] < sum(r[8]["edges_unique"] for r in refs)
+    import os
+    os.environ["RRTX_RS_EAGER"] = "1"
+    try:
+        eag = util.run_gpu_rrt_rs(g, seeds[:24])
+    finally:
+        del os.environ["RRTX_RS_EAGER"]
+    for i in range(24):
+        util.assert_tree_equal(eag["trees"][i], out["trees"][i], "eager vs lazy, seed %d" % seeds[i])
+        assert np.array_equal(eag["polys"][i][1], out["polys"][i][1])
+    assert eag["stats"]["edges_unique"] == sum(r[8]["edges_unique"] for r in refs[:24])
 
 
 def test_reeds_shepp_host_class_drop_in(gpu):
