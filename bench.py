@@ -260,6 +260,16 @@ def main():
             "q16_fallbacks_last_step": stats.get("q16_fallbacks"),
             "exact_rescans_last_step": stats.get("exact_rescans"),
         }
+        if c6:
+            line["plans_per_s"] = len(all_pc) * steps_done / tmax
+            line["edges_steered_per_iteration"] = tot_edges_u / max(iters * ngpu, 1)
+            line["roofline"]["note"] = (
+                "rrt_06's iteration is closed-form f64 trigonometry (48 Reeds-Shepp word evaluations per steer, glibc-exact "
+                "sin/cos/atan2/acos/asin/pow replicas), not a stream: the kernel is f64-VALU / latency bound and its HBM "
+                "figure (16 B per node and scan + 24 B per polyline point written) is far below the HBM roof by "
+                "construction.  `value` counts the edges the device steers (lazy candidate order, DESIGN.md 5.7); the "
+                "reference and the oracle steer every near candidate (RRTX_RS_EAGER=1 does the same on the device), so "
+                "compare plans_per_s with cpu_baseline.plans_per_s, not the edge rates")
         if not a.no_cpu_baseline and ngpu == 1:   # the CPU baseline is reported by the single-GPU run only
             import oracle
             tc = time.perf_counter()
@@ -286,6 +296,19 @@ def main():
                 kc = util.c2_kwargs(a.cpu_iters, m=a.obstacles)
                 r = oracle.plan(seed=1, exact_pow=False, **kc)
             tc = time.perf_counter() - tc
+            if c6:
+                line["cpu_baseline"] = {"value": r["stats"]["edges_unique"] / tc, "unit": "edge expansions/s", "cores": 1,
+                                        "kind": "port", "plans_per_s": ncpu / tc,
+                                        "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference), the first %d "
+                                                  "instances (seeds 1..%d) of the same workload one after the other, %.1f s; "
+                                                  "every near candidate steered as the reference does"
+                                                  % (ncpu, ncpu, tc)}
+                print(json.dumps(line), flush=True)
+                h.close()
+                if dist is not None:
+                    dist.barrier()
+                    dist.destroy_process_group()
+                return
             line["cpu_baseline"] = {"value": r["stats"]["edges_unique"] / tc, "unit": "edge expansions/s", "cores": 1,
                                     "kind": "port",
                                     "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference), 1 instance, "
