@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stress parity (GPU box): many seeds per planner, GPU trees vs the golden-pinned oracle, bit for bit.
-Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration)"""
+Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 runs that block only)"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -30,6 +30,19 @@ def o03(a):
     sd, it, sob = a
     r = oracle.plan_rrt_dubins(G03["start"], G03["goal"], G03["obstacles"], G03["rand_area"], it, seed=sd,
                                robot_radius=float(G03["robot_radius"]), goal_sample_rate=10, sobol=bool(sob))
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
+G06 = util.load_golden(util.GOLDEN + "/rrt06_drv_s7_it750.npz")
+
+
+def o06(a):
+    import oracle
+    sd, g = a
+    r = oracle.plan_rrt_rs(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]), seed=sd,
+                           curvature=float(g["curvature"]), robot_radius=float(g["robot_radius"]),
+                           expand_dis=float(g["expand_dis"]), connect_circle_dist=float(g["connect_circle_dist"]),
+                           step_size=float(g["step_size"]), search_until_max_iter=bool(int(g["search_until_max_iter"])))
     return r["x"], r["y"], r["cost"], r["parent"]
 
 
@@ -68,6 +81,18 @@ if __name__ == "__main__":
     total = 0
     with ProcessPoolExecutor(max_workers=14) as ex:
         seeds = list(range(1, CNT + 1))
+        # rrt_06 (lazy candidate order on the device vs the oracle steering every candidate)
+        for nm, upd in (("driver, 750 it", {}), ("driver, 2000 it", {"max_iter": 2000}),
+                        ("driver, early exit", {"search_until_max_iter": 0, "max_iter": 1500}),
+                        ("curvature 1, step 0.2, radius 0, goal yaw 1.2, 1000 it",
+                         {"curvature": 1.0, "step_size": 0.2, "robot_radius": 0.0, "max_iter": 1000,
+                          "goal": np.array([10.0, 9.0, 1.2])})):
+            g = dict(G06); g.update(upd)
+            out = util.run_gpu_rrt_rs(g, seeds)
+            total += compare("rrt_06 " + nm, out["trees"], list(ex.map(o06, [(s, g) for s in seeds])))
+        if os.environ.get("STRESS_ONLY") == "rrt06":
+            print("TOTAL mismatches", total)
+            sys.exit(1 if total else 0)
         # rrt_05
         g = dict(G05); g["max_iter"] = 4000
         out = util.run_gpu_dubins(g, seeds)
