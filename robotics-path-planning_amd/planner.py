@@ -591,14 +591,22 @@ class BatchPlanner:
 
     def __init__(self, algo, seeds, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
                  goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=False,
-                 connect_circle_dist=50.0, search_until_max_iter=False, device=0, starts=None, goals=None):
-        a = {"rrt": _abi.ALGO_RRT, "rrt_star": _abi.ALGO_RRT_STAR}[algo]
+                 connect_circle_dist=50.0, search_until_max_iter=False, device=0, starts=None, goals=None,
+                 curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.2):
+        """algo: "rrt" (rrt_01/02), "rrt_star" (rrt_04), and the pose planners (start / goal = [x, y, yaw]; curvature,
+        goal thresholds and, for Reeds-Shepp, step_size as in their constructors): "rrt_dubins" (rrt_03),
+        "rrt_star_dubins" (rrt_05), "rrt_star_reeds_shepp" (rrt_06)."""
+        a = {"rrt": _abi.ALGO_RRT, "rrt_star": _abi.ALGO_RRT_STAR, "rrt_dubins": _abi.ALGO_RRT_DUBINS,
+             "rrt_star_dubins": _abi.ALGO_DUBINS, "rrt_star_reeds_shepp": _abi.ALGO_RS}[algo]
         self.seeds = list(seeds)
+        self.pose = a in (_abi.ALGO_RRT_DUBINS, _abi.ALGO_DUBINS, _abi.ALGO_RS)
+        self.algo = a
         self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
                              play_area=play_area, robot_radius=robot_radius,
                              sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT,
                              connect_circle_dist=connect_circle_dist, search_until_max_iter=search_until_max_iter,
-                             n_instances=len(self.seeds), device=device)
+                             n_instances=len(self.seeds), device=device, curvature=curvature, goal_yaw_th=goal_yaw_th,
+                             goal_xy_th=goal_xy_th, step_size=step_size)
         self.h.set_obstacles(obstacle_list)
         self.h.seed_instances(self.seeds)
         if starts is not None or goals is not None:
@@ -616,7 +624,17 @@ class BatchPlanner:
         return self.h.get_tree(i)
 
     def path(self, i):
-        return self.h.get_path(i)
+        """The course `planning()` returns: (n, 2), or (n, 3) with the yaw column for "rrt_star_reeds_shepp"."""
+        p = self.h.get_path(i)
+        if p is not None and self.algo == _abi.ALGO_RS:
+            p = np.column_stack([p, self.h.get_path_yaw(i)])
+        return p
+
+    def yaw(self, i):
+        return self.h.get_yaw(i)
+
+    def polylines(self, i):
+        return self.h.get_polylines(i)
 
     def smooth(self, max_iter):
         """path_smoothing(path, max_iter, obstacle_list) (rrt_04:1447-1479) on every planned path, on the device, each

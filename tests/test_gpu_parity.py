@@ -393,6 +393,38 @@ def test_reeds_shepp_host_class_drop_in(gpu):
     assert len(smoothed) >= 2 and smoothed[0] == [float(g["goal"][0]), float(g["goal"][1])]
 
 
+def test_batch_planner_pose_planners(gpu):
+    """BatchPlanner over the pose planners: instance i = the single-instance class seeded with seeds[i]."""
+    import random
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt06_drv_s42_it200.npz")
+    obst = [tuple(o) for o in g["obstacles"]]
+    bp = rrt_amd.BatchPlanner("rrt_star_reeds_shepp", [42, 43, 44], list(g["start"]), list(g["goal"]), obst,
+                              list(g["rand_area"]), expand_dis=3.0, goal_sample_rate=10, max_iter=200, robot_radius=0.6,
+                              search_until_max_iter=True, curvature=2.0, step_size=0.1)
+    try:
+        bp.plan()
+        assert np.array_equal(bp.path(0), g["path"]) and np.array_equal(bp.yaw(0), g["yaw"])
+        random.seed(44)
+        one = rrt_amd.RRTStarReedsShepp(list(g["start"]), list(g["goal"]), obst, list(g["rand_area"]), goal_sample_rate=10,
+                                        max_iter=200, robot_radius=0.6, curvature=2.0, step_size=0.1)
+        p = one.planning(animation=False)
+        assert (p is None) == (bp.path(2) is None) and (p is None or np.array_equal(np.array(p), bp.path(2)))
+        assert np.array_equal(bp.tree(2)[2], one.tree[2])
+    finally:
+        bp.close()
+    g5 = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it150.npz")
+    bp = rrt_amd.BatchPlanner("rrt_star_dubins", [42, 7], list(g5["start"]), list(g5["goal"]),
+                              [tuple(o) for o in g5["obstacles"]], list(g5["rand_area"]), goal_sample_rate=10, max_iter=150,
+                              search_until_max_iter=True, curvature=1.0)
+    try:
+        bp.plan()
+        util.assert_tree_equal(bp.tree(0), (g5["x"], g5["y"], g5["cost"], g5["parent"]), "rrt05 via BatchPlanner")
+        assert np.array_equal(bp.polylines(0)[1], g5["poly_x"])
+    finally:
+        bp.close()
+
+
 def test_gpu_dubins_batch_equals_oracle(gpu):
     import oracle
     g = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it500.npz")
