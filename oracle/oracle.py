@@ -214,6 +214,14 @@ def plan_rrt_dubins(start, goal, obstacles, rand_area, max_iter=200, seed=None, 
                        _sobol=sobol, _play_area=play_area)
 
 
+def set_lazy_order(on):
+    """Test switch of rrt_oracle.c (orc_set_lazy_order): candidate order of the device's pose-tree kernels."""
+    L = lib()
+    L.orc_set_lazy_order.argtypes = [C.c_int]
+    L.orc_set_lazy_order.restype = None
+    L.orc_set_lazy_order(int(bool(on)))
+
+
 def plan_rrt_rs(start, goal, obstacles, rand_area, max_iter=500, seed=None, rng=None, curvature=1.0, robot_radius=0.0,
                 expand_dis=3.0, connect_circle_dist=50.0, goal_yaw_th=None, goal_xy_th=0.5, step_size=0.2, trace=False,
                 search_until_max_iter=True):

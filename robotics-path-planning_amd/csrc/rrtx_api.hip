@@ -520,6 +520,8 @@ int rrtx_plan(rrtx_handle* h) {
   // on the handle's own stream: it is a non-blocking stream, work queued on the null stream is not ordered with it
   if (is_pose_tree(c.algo)) HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
   if (const char* e = getenv("RRTX_RS_EAGER")) h->da.eager = atoi(e) != 0;
+  h->da.lazy = 0;
+  if (const char* e = getenv("RRTX_DUBINS_LAZY")) h->da.lazy = atoi(e) != 0;
   rppi::InformedArgs ia;
   for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
   ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057

@@ -460,6 +460,34 @@ def test_gpu_dubins_many_seeds_equal_oracle(gpu):
         util.assert_tree_equal(out["trees"][i], refs[i], "seed %d" % s)
 
 
+def test_gpu_dubins_lazy_candidate_order(gpu):
+    """RRTX_DUBINS_LAZY=1 (opt-in): the rrt_05 kernel with the lazy candidate order of the rrt_06 kernel builds the
+    goldens' trees (incl. the run where a node is rewired twice in one iteration) and the oracle's for 48 long runs."""
+    import os
+    from concurrent.futures import ProcessPoolExecutor
+    os.environ["RRTX_DUBINS_LAZY"] = "1"
+    try:
+        for path in util.golden_files("rrt05_drv"):
+            g = util.load_golden(path)
+            out = util.run_gpu_dubins(g, [int(g["seed"])])
+            util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+            assert np.array_equal(out["yaws"][0], g["yaw"]) and np.array_equal(out["polys"][0][1], g["poly_x"])
+            if len(g["path"]):
+                assert np.array_equal(out["paths"][0], g["path"])
+        g = {k: v for k, v in util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it500.npz").items()}
+        seeds = list(range(360, 408))
+        out = util.run_gpu_dubins(g, seeds, max_iter=3000)
+        lazy_edges = out["stats"]["edges_unique"]
+    finally:
+        del os.environ["RRTX_DUBINS_LAZY"]
+    with ProcessPoolExecutor(max_workers=8) as ex:
+        refs = list(ex.map(_orc05, [(g, s, 3000) for s in seeds]))
+    for i, s in enumerate(seeds):
+        util.assert_tree_equal(out["trees"][i], refs[i], "seed %d" % s)
+    eager = util.run_gpu_dubins(g, seeds[:8], max_iter=3000)
+    assert lazy_edges / 48 < eager["stats"]["edges_unique"] / 8 / 4
+
+
 def test_dubins_host_class_drop_in(gpu):
     import random
     import rrt_amd

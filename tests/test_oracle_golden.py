@@ -137,6 +137,49 @@ def test_reeds_shepp_rrt_star_oracle_matches_reference_golden(path):
     assert np.array_equal(r["tr_nearest"][:n], g["tr_nearest"]) and np.array_equal(r["tr_ryaw"][:n], g["tr_ryaw"])
 
 
+def test_lazy_candidate_order_builds_the_same_tree_dubins():
+    """The same argument for rrt_05 (the kernel's opt-in RRTX_DUBINS_LAZY=1): oracle in the lazy order vs the goldens."""
+    import oracle
+    oracle.set_lazy_order(True)
+    try:
+        for path in util.golden_files("rrt05_drv"):
+            g = util.load_golden(path)
+            r = oracle.plan_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], int(g["max_iter"]),
+                                   seed=int(g["seed"]))
+            util.assert_tree_equal((r["x"], r["y"], r["cost"], r["parent"]), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+            assert np.array_equal(r["poly_x"], g["poly_x"]) and r["rng"].pos == int(g["rng_pos_after"])
+    finally:
+        oracle.set_lazy_order(False)
+
+
+def test_lazy_candidate_order_builds_the_same_tree():
+    """The rrt_06 kernel steers choose_parent / rewire candidates lazily (rrt_rs.hip.h); the argument that this cannot
+    change the tree, checked on the CPU: the oracle in that order vs the oracle in the reference's order (every candidate
+    steered), 40 seeds of the driver scene and 12 of a second scene; it must also steer far fewer edges."""
+    import oracle
+    g = util.load_golden(util.GOLDEN + "/rrt06_drv_s42_it200.npz")
+    cases = [(s, dict(curvature=2.0, robot_radius=0.6, step_size=0.1), [10.0, 9.0, 0.0], 400) for s in range(200, 240)]
+    cases += [(s, dict(curvature=1.0, robot_radius=0.0, step_size=0.2), [10.0, 9.0, 1.2], 600) for s in range(300, 312)]
+    e_eager = e_lazy = 0
+    for seed, kw, goal, it in cases:
+        ref = oracle.plan_rrt_rs(g["start"], goal, g["obstacles"], g["rand_area"], it, seed=seed, **kw)
+        oracle.set_lazy_order(True)
+        try:
+            lz = oracle.plan_rrt_rs(g["start"], goal, g["obstacles"], g["rand_area"], it, seed=seed, **kw)
+        finally:
+            oracle.set_lazy_order(False)
+        util.assert_tree_equal((lz["x"], lz["y"], lz["cost"], lz["parent"]), (ref["x"], ref["y"], ref["cost"], ref["parent"]),
+                               "seed %d" % seed)
+        assert np.array_equal(lz["yaw"], ref["yaw"]) and np.array_equal(lz["poly_x"], ref["poly_x"])
+        assert (lz["path"] is None) == (ref["path"] is None)
+        if ref["path"] is not None:
+            assert np.array_equal(lz["path"], ref["path"]) and np.array_equal(lz["path_yaw"], ref["path_yaw"])
+        assert lz["rng"].pos == ref["rng"].pos
+        e_eager += ref["stats"]["edges_unique"]
+        e_lazy += lz["stats"]["edges_unique"]
+    assert e_lazy * 4 < e_eager
+
+
 @pytest.mark.parametrize("path", util.golden_files("rrt03"), ids=lambda p: p.split("/")[-1][:-4])
 def test_rrt_dubins_oracle_matches_reference_golden(path):
     """rrt_03 RRT with Dubins steer (pseudo-random and 3-D Sobol sampler): poses, Dubins-length costs, parents, every
