@@ -521,6 +521,8 @@ int rrtx_plan(rrtx_handle* h) {
   if (is_pose_tree(c.algo)) HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
   if (const char* e = getenv("RRTX_RS_EAGER")) h->da.eager = atoi(e) != 0;
   h->da.lazy = 0;
+  h->da.filter = 1;
+  if (const char* e = getenv("RRTX_DUBINS_FILTER")) h->da.filter = atoi(e) != 0;
   if (const char* e = getenv("RRTX_DUBINS_LAZY")) h->da.lazy = atoi(e) != 0;
   rppi::InformedArgs ia;
   for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];

@@ -484,7 +484,18 @@ def test_gpu_dubins_lazy_candidate_order(gpu):
         refs = list(ex.map(_orc05, [(g, s, 3000) for s in seeds]))
     for i, s in enumerate(seeds):
         util.assert_tree_equal(out["trees"][i], refs[i], "seed %d" % s)
-    eager = util.run_gpu_dubins(g, seeds[:8], max_iter=3000)
+    # default = filtered candidate stages; RRTX_DUBINS_FILTER=0 = every candidate steered like the reference
+    flt = util.run_gpu_dubins(g, seeds[:8], max_iter=3000)
+    os.environ["RRTX_DUBINS_FILTER"] = "0"
+    try:
+        eager = util.run_gpu_dubins(g, seeds[:8], max_iter=3000)
+    finally:
+        del os.environ["RRTX_DUBINS_FILTER"]
+    for i in range(8):
+        util.assert_tree_equal(flt["trees"][i], refs[i], "filtered, seed %d" % seeds[i])
+        util.assert_tree_equal(eager["trees"][i], refs[i], "unfiltered, seed %d" % seeds[i])
+        assert np.array_equal(flt["polys"][i][1], eager["polys"][i][1])
+    assert flt["stats"]["edges_unique"] * 2 < eager["stats"]["edges_unique"]
     assert lazy_edges / 48 < eager["stats"]["edges_unique"] / 8 / 4
 
 
