@@ -260,6 +260,14 @@ def main():
             "q16_fallbacks_last_step": stats.get("q16_fallbacks"),
             "exact_rescans_last_step": stats.get("exact_rescans"),
         }
+        if c5 and not c6:
+            line["plans_per_s"] = len(all_pc) * steps_done / tmax
+            line["edges_steered_per_iteration"] = tot_edges_u / max(iters * ngpu, 1)
+            line["value_note"] = ("`value` counts the Dubins edges the device steers.  The default build steers only the "
+                                  "candidates that can change the result (DESIGN.md 5.5, filtered candidate stages: same "
+                                  "trees, ~8x fewer edges); RRTX_DUBINS_FILTER=0 steers every near candidate as the "
+                                  "reference and the CPU baseline do -- compare iterations_per_s / plans_per_s across "
+                                  "builds, not the edge rates")
         if c6:
             line["plans_per_s"] = len(all_pc) * steps_done / tmax
             line["edges_steered_per_iteration"] = tot_edges_u / max(iters * ngpu, 1)
