@@ -122,7 +122,7 @@ def test_bitstar_core_against_goldens_and_oracle(builddir):
 
 
 def test_reeds_shepp_core_against_reference_kat(builddir):
-    """rpp_rs.h (host + device source of the Reeds-Shepp steer, groundwork for rrt_06) against the reference's 600
+    """rpp_rs.h (host + device source of the Reeds-Shepp steer of the rrt_06 kernel) against the reference's 600
     known-answer vectors: word, lengths, every point and yaw, None and raising cases -- bit for bit."""
     import struct
     import numpy as np

@@ -47,7 +47,7 @@ def test_device_arithmetic_replicas(gpu):
     assert all(got[i] == math.acos(u[i]) for i in range(n)), "acos"
     got = sel(9, u, b)
     assert all(got[i] == math.asin(u[i]) for i in range(n)), "asin"
-    # Reeds-Shepp steer core (rpp_rs.h, groundwork for rrt_06) on the device vs the oracle's restatement
+    # Reeds-Shepp steer core (rpp_rs.h, the steer of the rrt_06 kernel) on the device vs the oracle's restatement
     m = 3000
     gx = (rng.random(m) * 2 - 1) * 8
     gy = (rng.random(m) * 2 - 1) * 8
