@@ -313,13 +313,29 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     __syncthreads();
     const double rx = sh.rx, ry = sh.ry, ryaw = sh.ryaw;
     // ---------------- get_nearest_node_index :1728-1734 (x, y only; first minimum)
+    // The reference's distance is dx**2 + dy**2 with libm pow (rpp::py_d2); correctly rounded squares
+    // (rpp::fast_d2) are within 2^-51 relative of it, so they decide everything except near-ties: the exact form is
+    // evaluated only for nodes within FILTER_EPS of the fast minimum.
+    double fb = rpp::dinf();
+    for (int i = lane; i < n; i += TPB) {
+      const double f = rpp::fast_d2(x[i] - rx, y[i] - ry);
+      fb = f < fb ? f : fb;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      const double of = __shfl_xor(fb, o);
+      fb = of < fb ? of : fb;
+    }
+    const double fthr = fb * (1.0 + rppk::FILTER_EPS);
     double bd = rpp::dinf();
     int ni = 0x7fffffff;
     for (int i = lane; i < n; i += TPB) {
-      const double d = rpp::py_d2(x[i] - rx, y[i] - ry);
-      if (d < bd) {
-        bd = d;
-        ni = i;
+      const double dx = x[i] - rx, dy = y[i] - ry;
+      if (rpp::fast_d2(dx, dy) <= fthr) {
+        const double d = rpp::py_d2(dx, dy);
+        if (d < bd) {
+          bd = d;
+          ni = i;
+        }
       }
     }
     wave_argmin(bd, ni);
@@ -338,12 +354,26 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
       __syncthreads();
       // ---------------- find_near_nodes :1839-1863
       const double r2 = c.r2tab[n + 1];
-      int k = 0;
+      // stage 1: nodes whose fast distance is not clearly outside the ball, in index order (a superset of the hits)
+      int kc = 0;
+      const double r2hi = r2 * (1.0 + rppk::FILTER_EPS);
       for (int base = 0; base < n; base += TPB) {
         const int i = base + lane;
+        const bool maybe = i < n && rpp::fast_d2(x[i] - nx, y[i] - ny) <= r2hi;
+        const unsigned long long b = __ballot(maybe);
+        if (maybe) mark[kc + __popcll(b & ((1ULL << lane) - 1ULL))] = i;
+        kc += __popcll(b);
+      }
+      __syncthreads();
+      // stage 2: the reference's own distance for those, the <= r**2 test on it, ordered compaction
+      int k = 0;
+      for (int base = 0; base < kc; base += TPB) {
+        const int q = base + lane;
         double d = 0.0;
+        int i = 0;
         bool hit = false;
-        if (i < n) {
+        if (q < kc) {
+          i = mark[q];
           d = rpp::py_d2(x[i] - nx, y[i] - ny);
           hit = d <= r2;
         }
