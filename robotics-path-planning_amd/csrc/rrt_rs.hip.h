@@ -17,9 +17,14 @@
 //   * the course's points are independent once the segment origins are known: all lanes generate them
 //     (rpp::rs_point), test them against the LDS obstacle tile as they are produced (:1748-1762) and write them
 //     behind the instance's polyline pool, where they stay if the edge is kept.
-// choose_parent / rewire walk the near list in the reference's order, one cooperative edge after the other, so
-// repeated entries of near_inds (`dist_list.index`, :1861) and nodes moved by an earlier rewire are seen exactly
-// as the reference sees them.  Cost propagation is a level-synchronous sweep over the parent array.
+// choose_parent / rewire steer one cooperative edge after the other, and only the edges that can change the result
+// (da.eager = 0, the default): a candidate's cost does not depend on its steer, so choose_parent tries candidates in
+// ascending (cost, list position) order until one is feasible, and rewire walks near_inds in the reference's order but
+// steers an entry only when improved_cost (:1888) holds for the node's current pose and cost -- repeated entries of
+// near_inds (`dist_list.index`, :1861) and nodes moved by an earlier rewire are seen exactly as the reference sees
+// them.  da.eager = 1 (RRTX_RS_EAGER=1) steers every candidate like the reference; same trees either way (tests).
+// Scans use correctly rounded squares as a filter and the reference's pow-based distance for near-ties and hits.
+// Cost propagation is a level-synchronous sweep over the parent array.
 #pragma once
 #include "rpp_rs.h"
 #include "rrt_dubins.hip.h"
