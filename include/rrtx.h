@@ -127,7 +127,8 @@ int rrtx_set_rng_state(rrtx_handle* h, int32_t instance, const uint32_t* mt624, 
 int rrtx_get_rng_state(rrtx_handle* h, int32_t instance, uint32_t* mt624, int32_t* pos);
 /* convenience: state after `random.seed(seed)` for instances first..first+count-1 */
 int rrtx_seed_instances(rrtx_handle* h, int32_t first, int32_t count, const uint64_t* seeds);
-/* per-instance start / goal for batches (default: the ctor's) */
+/* per-instance start / goal for batches (default: the ctor's).  The pose planners (RRTX_ALGO_DUBINS / _RRT_DUBINS / _RS)
+ * take x, y per instance; start and goal yaw are the ctor's for every instance of a handle. */
 int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, const double* goal3);
 /* RRTX_ALGO_BITSTAR: per-instance rotation `C` (upper-left 2x2, row major) and cMin = hypot(start-goal)/1.5, computed
  * by the host with numpy exactly as rrt_08:189-202 does (default: the ctor's informed_rot / informed_c_min). */

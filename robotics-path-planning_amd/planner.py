@@ -595,7 +595,8 @@ class BatchPlanner:
                  curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.2):
         """algo: "rrt" (rrt_01/02), "rrt_star" (rrt_04), and the pose planners (start / goal = [x, y, yaw]; curvature,
         goal thresholds and, for Reeds-Shepp, step_size as in their constructors): "rrt_dubins" (rrt_03),
-        "rrt_star_dubins" (rrt_05), "rrt_star_reeds_shepp" (rrt_06)."""
+        "rrt_star_dubins" (rrt_05), "rrt_star_reeds_shepp" (rrt_06).  `starts` / `goals` give per-instance x, y; for
+        the pose planners the start and goal yaw are `start[2]` / `goal[2]` for every instance."""
         a = {"rrt": _abi.ALGO_RRT, "rrt_star": _abi.ALGO_RRT_STAR, "rrt_dubins": _abi.ALGO_RRT_DUBINS,
              "rrt_star_dubins": _abi.ALGO_DUBINS, "rrt_star_reeds_shepp": _abi.ALGO_RS}[algo]
         self.seeds = list(seeds)
