@@ -51,6 +51,34 @@ def test_abi_library_exports_every_declared_symbol():
     assert set(rrt_amd._abi.EXPORTS) <= declared
 
 
+def test_python_binding_mirrors_the_header():
+    """The ctypes mirror (robotics-path-planning_amd/_abi.py) against include/rrtx.h: ABI version, algorithm ids, the
+    size of rrtx_params as the C compiler lays it out, and every binding has argtypes (a missing one truncates the
+    64-bit handle)."""
+    import subprocess
+    import tempfile
+    import rrt_amd
+    A = rrt_amd._abi
+    hdr = open(os.path.join(util.ROOT, "include", "rrtx.h")).read()
+    assert int(re.search(r"#define RRTX_ABI_VERSION (\d+)", hdr).group(1)) == A.RRTX_ABI_VERSION
+    ids = dict((k, int(v)) for k, v in re.findall(r"(RRTX_ALGO_[A-Z_]+) = (\d+)", hdr))
+    assert ids == {"RRTX_ALGO_RRT": A.ALGO_RRT, "RRTX_ALGO_RRT_STAR": A.ALGO_RRT_STAR, "RRTX_ALGO_INFORMED": A.ALGO_INFORMED,
+                   "RRTX_ALGO_DUBINS": A.ALGO_DUBINS, "RRTX_ALGO_BITSTAR": A.ALGO_BITSTAR,
+                   "RRTX_ALGO_RRT_DUBINS": A.ALGO_RRT_DUBINS, "RRTX_ALGO_RS": A.ALGO_RS}
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sz.c")
+        open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "rrtx.h"\nint main(void) { printf("%zu %zu %zu", '
+                             'sizeof(rrtx_params), offsetof(rrtx_params, step_size), sizeof(rrtx_stats)); return 0; }\n')
+        exe = os.path.join(d, "sz")
+        subprocess.check_call(["gcc", "-I", os.path.join(util.ROOT, "include"), "-o", exe, src])
+        sz, off, ssz = (int(v) for v in subprocess.check_output([exe]).split())
+    assert sz == ctypes.sizeof(A.Params) and off == A.Params.step_size.offset and ssz == ctypes.sizeof(A.Stats)
+    L = A.load()
+    for name in A.EXPORTS:
+        if name not in ("rrtx_abi_version", "rrtx_device_count"):
+            assert getattr(L, name).argtypes is not None, name
+
+
 def test_no_cpu_fallback_without_device():
     """Without a GPU the product path must fail loudly, not plan on the CPU."""
     import rrt_amd
