@@ -7,131 +7,198 @@ max_iter 105 000 => ~100k nodes), many independent instances per GPU.
 
 One "step" = one full planning pass of the hot path over one batch: `--instances` independent trees per
 GPU (seeds rank*B+1 ...), each grown for `--max-iter` iterations by the HIP kernels through the C ABI
-(librrtx.so).  Inputs (obstacles, RNG states) are resident in HBM before the timed region.  N GPUs = N
-processes (torch.distributed / RCCL), instances sharded with no data-path collective; the only collective
-is the final all_gather of the 16-byte per-instance result records.  `value` = edge expansions of all ranks
-per step / max-over-ranks step time.
+(librrtx.so).  Inputs (obstacles, RNG states) are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes (SURVEY.md 8d:
-sum over iterations of 32*n + 48*k + 24*M + 28) / HIP-event time of the planner kernel launches; the fused
-single-pass figure (16*n per iteration) is reported next to it.
-`cpu_baseline` = the CPU oracle (oracle/rrt_oracle.c, "port") on one host core on a bounded sample.
+  python bench.py --gpus N --steps K --warmup W
+
+* N > 1 without a launcher: this process starts N rank processes itself (RANK / LOCAL_RANK / WORLD_SIZE /
+  MASTER_ADDR=127.0.0.1 / MASTER_PORT set, before anything touches the GPU), waits for them and exits non-zero if
+  one fails.  Under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the launcher's
+  environment is used as it is.  One process per GPU, instances sharded with no data-path collective; the only
+  collective is the final all_gather of the 16-byte per-instance result records (RCCL).
+* Time budget: a full-size C2 step takes tens of seconds.  `--max-seconds` (default 240, counted from PROCESS START:
+  allocation, CPU baseline and warm-up included) bounds the run: the loop stops after the last step that fits and the
+  JSON line reports the steps actually timed in `steps` (`steps_requested` keeps K).  The workload is never shrunk.
+* The CPU baseline (oracle/rrt_oracle.c on the host cores, single thread and one instance per core) runs BEFORE the
+  timed loop, bounded to ~12 s.
+* Prints ONE JSON line (rank 0) on stdout.  If the process receives SIGTERM after at least one timed step, the line
+  for the steps completed so far is printed before exiting.
 """
 import argparse
+import hashlib
 import json
-import math
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
+T_PROCESS_START = time.perf_counter()
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
-def main():
+
+def elapsed():
+    return time.perf_counter() - T_PROCESS_START
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=int(os.environ.get("RRTX_BENCH_INSTANCES", "4096")),
-                    help="planning instances per GPU (weak scaling)")
-    ap.add_argument("--max-iter", type=int, default=int(os.environ.get("RRTX_BENCH_MAX_ITER", "105000")))
+    ap.add_argument("--instances", type=int, default=None, help="planning instances per GPU (weak scaling)")
+    ap.add_argument("--max-iter", type=int, default=None)
     ap.add_argument("--obstacles", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5", "c6"],
-                    help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations (the headline metric); c3: rrt_07 Informed RRT* "
-                         "with the Sobol sampler, 200 obstacles (SURVEY 8d), default 20k iterations / 1024 instances; "
-                         "c5: rrt_05 RRT*-Dubins, driver constants, default 5000 iterations / 1536 instances; "
-                         "c4: rrt_08 BIT*, driver constants, per-instance start/goal (SURVEY 8d), 80 iterations; "
+                    help="c2: rrt_04 RRT*, 50 obstacles, 105k iterations, 4096 instances/GPU (the headline metric); "
+                         "c3: rrt_07 Informed RRT*, Sobol sampler, 200 obstacles, 20k iterations / 1024 instances; "
+                         "c4: rrt_08 BIT*, driver constants, per-instance start/goal, 80 iterations / 4096 instances; "
+                         "c5: rrt_05 RRT*-Dubins, driver constants, 5000 iterations / 1536 instances; "
                          "c6: rrt_06 RRT*-Reeds-Shepp, driver constants, 750 iterations / 16384 instances")
-    ap.add_argument("--cpu-iters", type=int, default=40000, help="iterations of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=float(os.environ.get("RRTX_BENCH_CPU_SECONDS", "12")),
+                    help="wall-clock bound of the CPU baseline (single-thread leg + all-cores leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
                     help="iterations of a warm-up step (0 = same as a timed step); a warm-up only has to page in the "
-                         "code objects and allocations, a full-size pass takes ~40 s")
-    ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("RRTX_BENCH_MAX_SECONDS", "1500")),
-                    help="stop timing further steps once this much time has been spent (the JSON reports the steps "
-                         "actually timed)")
-    a = ap.parse_args()
+                         "code objects and allocations, a full-size C2 pass takes tens of seconds")
+    ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("RRTX_BENCH_MAX_SECONDS", "240")),
+                    help="time budget from process start (setup, CPU baseline and warm-up included); the JSON reports "
+                         "the steps actually timed")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no device: every rank reports synthetic counters (gloo backend); exercises the launch, the "
+                         "collectives and the report only -- the line carries \"dry_run\": true and no throughput")
+    return ap.parse_args(argv)
 
-    import numpy as np
-    import util
-    c3 = a.workload == "c3"
-    c6 = a.workload == "c6"
-    c5 = a.workload == "c5" or c6     # c6 shares c5's reporting; only the planner and its constants differ
-    if a.obstacles is None:
-        a.obstacles = 200 if c3 else ((7 if c6 else 6) if c5 else 50)
-    if c6:
-        if "--max-iter" not in sys.argv:
-            a.max_iter = 750
-        if "--instances" not in sys.argv:
-            a.instances = 16384     # four rounds of 16 waves per CU
-        a.warmup_max_iter = 0
-    if c5 and not c6:
-        if "--max-iter" not in sys.argv:
-            a.max_iter = 5000
-        if "--instances" not in sys.argv:
-            a.instances = 1536      # two full rounds of 3 workgroups per CU
-    if c3:
-        if "--max-iter" not in sys.argv:
-            a.max_iter = 20000
-        if "--instances" not in sys.argv:
-            a.instances = 1024     # 4 workgroups of 256 threads per CU
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    torch = None
-    if a.gpus > 1 or world > 1 or os.environ.get("RRTX_BENCH_FORCE_DIST"):
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    ngpu = max(world, 1)
-    device = local_rank
+# ------------------------------------------------------------------------------------------------ self-launch
+def spawn_ranks(a):
+    """--gpus N without a launcher environment: start N rank processes (fresh interpreters; this parent never touches
+    the GPU and never re-execs), wait, propagate failure."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r if r > 0 else 1
+                    for q in pending:      # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        rc = 130
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
-    import importlib
-    import rrt_amd
-    sharding = importlib.import_module("robotics-path-planning_amd.sharding")
-    A = rrt_amd._abi
-    if a.workload == "c4":
-        bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu)
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-    kw = util.c2_kwargs(a.max_iter, m=a.obstacles)
-    if c3:
-        kw = dict(algo="informed", start=[2, 2], goal=[98, 98], obstacles=util.synth_map(11, a.obstacles, 0.3, 1.5),
-                  rand_area=[0, 100], expand_dis=0.5, goal_sample_rate=10, max_iter=a.max_iter, sobol=1)
-    if c5:   # rrt_05 driver constants (rrt_05:1804-1859)
-        kw = dict(algo="dubins", start=[0.0, 0.0, 0.0], goal=[10.0, 10.0, 0.0],
-                  obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)], rand_area=[-2, 15],
-                  expand_dis=3.0, goal_sample_rate=10, max_iter=a.max_iter)
-    if c6:   # rrt_06 driver constants (rrt_06:2012-2083)
-        kw = dict(algo="rs", start=[0.0, 0.0, 0.0], goal=[10.0, 9.0, 0.0],
-                  obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)],
-                  rand_area=[-2, 15], expand_dis=3.0, goal_sample_rate=10, max_iter=a.max_iter)
-    B = a.instances
-    seeds = sharding.shard_seeds(rank, B)          # rank r owns seeds r*B+1 .. (r+1)*B, no exchange while planning
-    cuda = torch.device("cuda", local_rank) if dist is not None else None
 
-    def make_handle(max_iter):
-        if c6:
+# ------------------------------------------------------------------------------------------------ workloads
+def csrc_hash():
+    """Identity of the device code the numbers belong to (PMC traffic files record it)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "robotics-path-planning_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".inc", ".hip")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class Workload:
+    """What differs between the configurations: handle construction, CPU sample, report strings."""
+
+    def __init__(self, a, np, util, rrt_amd):
+        self.a, self.np, self.util, self.rrt_amd = a, np, util, rrt_amd
+        w = a.workload
+        d_inst = {"c2": 4096, "c3": 1024, "c4": 4096, "c5": 1536, "c6": 16384}[w]
+        d_iter = {"c2": 105000, "c3": 20000, "c4": 80, "c5": 5000, "c6": 750}[w]
+        d_obst = {"c2": 50, "c3": 200, "c4": 6, "c5": 6, "c6": 7}[w]
+        env_i = os.environ.get("RRTX_BENCH_INSTANCES")
+        env_m = os.environ.get("RRTX_BENCH_MAX_ITER")
+        self.B = a.instances if a.instances is not None else (int(env_i) if env_i and w == "c2" else d_inst)
+        self.max_iter = a.max_iter if a.max_iter is not None else (int(env_m) if env_m and w == "c2" else d_iter)
+        self.M = a.obstacles if a.obstacles is not None else d_obst
+        if w != "c2":
+            a.warmup_max_iter = 0
+        if w == "c2":
+            self.kw = util.c2_kwargs(self.max_iter, m=self.M)
+        elif w == "c3":
+            self.kw = dict(algo="informed", start=[2, 2], goal=[98, 98], obstacles=util.synth_map(11, self.M, 0.3, 1.5),
+                           rand_area=[0, 100], expand_dis=0.5, goal_sample_rate=10, max_iter=self.max_iter, sobol=1)
+        elif w == "c5":   # rrt_05 driver constants (rrt_05:1804-1859)
+            self.kw = dict(algo="dubins", start=[0.0, 0.0, 0.0], goal=[10.0, 10.0, 0.0],
+                           obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2)][:self.M],
+                           rand_area=[-2, 15], expand_dis=3.0, goal_sample_rate=10, max_iter=self.max_iter)
+        elif w == "c6":   # rrt_06 driver constants (rrt_06:2012-2083)
+            self.kw = dict(algo="rs", start=[0.0, 0.0, 0.0], goal=[10.0, 9.0, 0.0],
+                           obstacles=[(5, 5, 1), (3, 6, 2), (3, 8, 2), (3, 10, 2), (7, 5, 2), (9, 5, 2), (8, 10, 1)][:self.M],
+                           rand_area=[-2, 15], expand_dis=3.0, goal_sample_rate=10, max_iter=self.max_iter)
+        else:             # c4: rrt_08 driver constants (rrt_08:633-665)
+            self.kw = dict(algo="bitstar", obstacles=[(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)],
+                           rand_area=[-2.0, 15.0], max_iter=self.max_iter)
+
+    # -- per-rank problem instances
+    def prepare(self, rank, sharding):
+        import random
+        self.seeds = sharding.shard_seeds(rank, self.B)     # rank r owns seeds r*B+1 .. (r+1)*B
+        if self.a.workload == "c4":
+            obst = self.kw["obstacles"]
+
+            def free_point(rng):
+                while True:
+                    x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
+                    if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
+                        return [x, y]
+            self.starts, self.goals, self.seeds = [], [], []
+            for i in range(rank * self.B, (rank + 1) * self.B):
+                rng = random.Random(2000 + i)
+                self.starts.append(free_point(rng))
+                self.goals.append(free_point(rng))
+                self.seeds.append(1000 + i)
+
+    def make_handle(self, max_iter, device):
+        A, np, kw, B, w = self.rrt_amd._abi, self.np, self.kw, self.B, self.a.workload
+        if w == "c6":
             h = A.Handle(A.ALGO_RS, kw["start"], kw["goal"], kw["rand_area"], 3.0, 0.5, 10, max_iter, robot_radius=0.6,
                          connect_circle_dist=50.0, search_until_max_iter=True, n_instances=B, device=device,
                          curvature=2.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.1)
-        elif c5:
+        elif w == "c5":
             h = A.Handle(A.ALGO_DUBINS, kw["start"], kw["goal"], kw["rand_area"], 3.0, 0.5, 10, max_iter, robot_radius=0.0,
                          connect_circle_dist=50.0, search_until_max_iter=True, n_instances=B, device=device,
                          curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5)
-        elif c3:
-            c_min, c = rrt_amd.informed_rotation(kw["start"], kw["goal"])
+        elif w == "c3":
+            c_min, c = self.rrt_amd.informed_rotation(kw["start"], kw["goal"])
             h = A.Handle(A.ALGO_INFORMED, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], 1.0,
                          kw["goal_sample_rate"], max_iter, sampler=A.SAMPLER_SOBOL, n_instances=B, device=device,
                          informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+        elif w == "c4":
+            c_min, c = self.rrt_amd.bitstar_rotation(self.starts[0], self.goals[0])
+            h = A.Handle(A.ALGO_BITSTAR, self.starts[0], self.goals[0], kw["rand_area"], 2.0, 1.0, 0, max_iter,
+                         n_instances=B, device=device, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]],
+                         informed_c_min=c_min)
         else:
             h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"],
                          kw["path_resolution"], kw["goal_sample_rate"], max_iter, play_area=None,
@@ -139,293 +206,453 @@ def main():
                          connect_circle_dist=kw["connect_circle_dist"], search_until_max_iter=True, n_instances=B,
                          device=device)
         h.set_obstacles(kw["obstacles"])
-        h.seed_instances(seeds)
+        h.seed_instances(self.seeds)
+        if w == "c4":
+            for i in range(B):
+                cm, ci = self.rrt_amd.bitstar_rotation(self.starts[i], self.goals[i])   # numpy SVD on the host (rrt_08:189-202)
+                h.set_instance(i, self.starts[i], self.goals[i])
+                h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
         return h
+
+    def step(self, h):
+        if self.a.workload == "c4":
+            h.seed_instances(self.seeds)   # BIT* handles keep their RNG position between plans
+        h.plan()                           # blocking: returns after the last kernel of the batch has finished
+
+    # -- report strings
+    def names(self):
+        w, B, mi, M = self.a.workload, self.B, self.max_iter, self.M
+        if w == "c2":
+            return ("RRT* edge expansions/sec + final path cost, %s tree (collision-checked edges evaluated on the device, "
+                    "distinct per iteration; %d iterations)" % ("100k-node" if mi >= 100000 else "%d-iteration" % mi, mi),
+                    "C2: rrt_04 RRT*, %d circle obstacles (map_seed 7) on 100x100, expand_dis 2.0, path_resolution 0.25, "
+                    "max_iter %d, %d instances/GPU (seeds 1..), MT sampler" % (M, mi, B),
+                    "rppk2t::rrt_star_kernel_v2<true>" if B > 2560 else "rppk2(s)::rrt_star_kernel_v2<true>")
+        if w == "c3":
+            return ("Informed RRT* edge expansions/sec + final path cost, %d-iteration tree" % mi,
+                    "C3: rrt_07 Informed RRT*, Sobol sampler, %d circle obstacles (map_seed 11, radii U(0.3,1.5)) on "
+                    "100x100, expand_dis 0.5, max_iter %d, %d instances/GPU (seeds 1..)" % (M, mi, B),
+                    "rppi::rrt_informed_kernel")
+        if w == "c4":
+            return ("BIT* edge-queue expansions/sec (edges popped and processed, rrt_08:262-318), %d-iteration plans" % mi,
+                    "C4: rrt_08 BIT*, driver constants (6 obstacles, rand_area [-2,15], maxIter %d), per-instance "
+                    "start/goal from random.Random(2000+i), planner seed 1000+i, %d instances/GPU" % (mi, B),
+                    "rppb::bitstar_wave_kernel")
+        if w == "c5":
+            return ("RRT*-Dubins edge expansions/sec + final path cost, %d-iteration tree" % mi,
+                    "C5: rrt_05 RRT*-Dubins, driver constants (%d obstacles, 17x17 area, curvature 1), max_iter %d, "
+                    "%d instances/GPU (seeds 1..)" % (M, mi, B), "rppd::rrt_dubins_kernel")
+        return ("RRT*-Reeds-Shepp edge expansions/sec + final path cost, %d-iteration tree" % mi,
+                "C6: rrt_06 RRT*-Reeds-Shepp, driver constants (%d obstacles, 17x17 area, curvature 2, step_size 0.1, "
+                "robot_radius 0.6), max_iter %d, %d instances/GPU (seeds 1..)" % (M, mi, B), "rppr::rrt_rs_kernel")
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_job(args):
+    """One oracle plan in a worker process (imports oracle/ -- the checker -- only here, in the cpu_baseline leg)."""
+    workload, kw, iters, seed, extra = args
+    import oracle
+    t = time.perf_counter()
+    if workload == "c2":
+        kc = dict(kw)
+        kc["max_iter"] = iters
+        r = oracle.plan(seed=seed, exact_pow=False, **kc)
+        st = r["stats"]
+        out = (st["edges_unique"], st["edges_ref"], 1)
+    elif workload == "c3":
+        kc = dict(kw)
+        kc.pop("algo")
+        kc["max_iter"] = iters
+        r = oracle.plan_informed(seed=seed, exact_pow=False, **kc)
+        st = r["stats"]
+        out = (st["edges_unique"], st["edges_ref"], 1)
+    elif workload == "c5":
+        r = oracle.plan_dubins(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], iters, seed=seed)
+        st = r["stats"]
+        out = (st["edges_unique"], st["edges_ref"], 1)
+    elif workload == "c6":   # `extra` = list of seeds
+        eu = er = n = 0
+        for sd in extra:
+            r = oracle.plan_rrt_rs(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], iters, seed=sd,
+                                   curvature=2.0, robot_radius=0.6, step_size=0.1)
+            eu += r["stats"]["edges_unique"]
+            er += r["stats"]["edges_ref"]
+            n += 1
+        out = (eu, er, n)
+    else:   # c4: `extra` = list of (start, goal, seed)
+        n = 0
+        for (s, g, sd) in extra:
+            oracle.plan_bitstar(s, g, kw["obstacles"], kw["rand_area"], iters, seed=sd)
+            n += 1
+        out = (0, 0, n)
+    return out + (time.perf_counter() - t,)
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, budget_s):
+    """the C restatement of the reference (oracle/rrt_oracle.c, pinned to the reference's goldens) on
+    the host cores of this box: (a) one instance on one thread, (b) one instance per core over all cores.  Bounded
+    sample of the same workload (fewer iterations per tree for C2/C3/C5: the CPU rate at full size is lower still)."""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    w, kw = wl.a.workload, wl.kw
+    try:
+        ncore = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncore = os.cpu_count() or 1
+    nwork = max(1, min(ncore, 16))
+    # sample sizes aimed at ~budget/3 per leg on one core (measured rates of the oracle on a 2.1 GHz Xeon core)
+    scale = max(0.25, min(4.0, budget_s / 12.0))
+    per_job = 1
+    if w == "c2":
+        iters = int(14000 * scale ** 0.5)    # time ~ n^2
+        unit = "edge expansions/s"
+    elif w == "c3":
+        iters = int(min(wl.max_iter, 12000 * scale ** 0.5))
+        unit = "edge expansions/s"
+    elif w == "c5":
+        iters = wl.max_iter
+        unit = "edge expansions/s"
+    elif w == "c6":
+        iters = wl.max_iter
+        unit = "edge expansions/s"
+        per_job = max(1, int(20 * scale))
+    else:
+        iters = wl.max_iter
+        unit = "plans/s"
+        per_job = max(1, int(240 * scale))
+
+    def job(k):
+        extra = None
+        if w == "c4":
+            idx = [(k * per_job + j) % wl.B for j in range(per_job)]
+            extra = [(wl.starts[i], wl.goals[i], wl.seeds[i]) for i in idx]
+        if w == "c6":
+            extra = [1 + k * per_job + j for j in range(per_job)]
+        return (w, kw, iters, 1 + k, extra)
+    ctx = mp.get_context("fork")     # forked before this process has touched the GPU
+    t0 = time.perf_counter()
+    with cf.ProcessPoolExecutor(max_workers=nwork, mp_context=ctx) as ex:
+        # (a) single thread: one job, alone on the machine
+        tA = time.perf_counter()
+        r1 = [ex.submit(_cpu_job, job(0)).result()]
+        tA = time.perf_counter() - tA
+        # (b) all cores: one job per worker, concurrently
+        tB = time.perf_counter()
+        rN = list(ex.map(_cpu_job, [job(k) for k in range(nwork)]))
+        tB = time.perf_counter() - tB
+    eu1, er1, pl1 = sum(r[0] for r in r1), sum(r[1] for r in r1), sum(r[2] for r in r1)
+    euN, erN, plN = sum(r[0] for r in rN), sum(r[1] for r in rN), sum(r[2] for r in rN)
+    plans = unit == "plans/s"
+    out = {"value": (plN if plans else euN) / tB, "unit": unit, "cores": nwork, "kind": "port",
+           "single_thread_value": (pl1 if plans else eu1) / tA,
+           "nproc": ncore, "cpu_model": cpu_model(),
+           "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference's goldens); same workload, %s; "
+                     "single thread: %d plan(s) in %.1f s; all cores: one job per core on %d cores in %.1f s (of %d "
+                     "visible cores); every near candidate steered as the reference does"
+                     % ("%d iterations per tree" % iters + ("" if per_job == 1 else ", %d plans per core" % per_job),
+                        pl1, tA, nwork, tB, ncore),
+           "seconds": time.perf_counter() - t0}
+    if not plans:
+        out["reference_equivalent_value"] = erN / tB
+        out["plans_per_s"] = plN / tB
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ dry run
+class DryHandle:
+    """--dry-run: no device, no planning.  Fixed synthetic counters so that the launch / collective / report path can
+    be exercised on a CPU-only machine (tests/test_bench_launch.py).  Never used for a measurement."""
+
+    def __init__(self, B, max_iter):
+        self.B, self.max_iter = B, max_iter
+
+    def plan(self):
+        time.sleep(0.02)
+
+    def get_stats(self):
+        n = self.B * self.max_iter
+        return dict(iterations=n, edges_unique=10 * n, edges_ref=100 * n, algorithmic_bytes=1000 * n,
+                    algorithmic_bytes_two_scan=8000 * n, kernel_ms=20.0, launches=1, near_unique_max=0, f32_fallbacks=0,
+                    q16_fallbacks=0, exact_rescans=0)
+
+    def get_results(self):
+        import numpy as np
+        return np.full(self.B, 1.0), np.full(self.B, self.max_iter, dtype=np.int32), np.full(self.B, 3, dtype=np.int32)
+
+    def close(self):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+
+    import numpy as np
+    import util
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and not (a.gpus == 1 and world == 1):
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    ngpu = world
+
+    import importlib
+    import rrt_amd
+    sharding = importlib.import_module("robotics-path-planning_amd.sharding")
+    wl = Workload(a, np, util, rrt_amd)
+    wl.prepare(rank, sharding)
+
+    # ---- CPU baseline first (rank 0 of a single-GPU run only): forks its workers before the GPU is touched
+    cpu = None
+    if not a.no_cpu_baseline and ngpu == 1 and not a.dry_run:
+        try:
+            cpu = cpu_baseline(wl, a.cpu_seconds)
+        except Exception as e:  # noqa: BLE001  (a missing checker must not lose the GPU measurement)
+            cpu = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    dist = None
+    torch = None
+    cuda = None
+    if ngpu > 1 or os.environ.get("RRTX_BENCH_FORCE_DIST"):
+        import torch
+        import torch.distributed as dist
+        if a.dry_run:
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            cuda = torch.device("cuda", local_rank)
+            dist.init_process_group(backend="nccl", device_id=cuda)
 
     def sync_all():
         if dist is not None:
             dist.barrier()
-            torch.cuda.synchronize()
+            if cuda is not None:
+                torch.cuda.synchronize()
 
-    h = make_handle(a.max_iter)
-    hw = h
-    if a.warmup_max_iter and a.warmup_max_iter != a.max_iter:
-        hw = make_handle(a.warmup_max_iter)
+    state = dict(steps_done=0, kernel_ms=0.0, alg=0, alg2=0, eu=0, er=0, iters=0, launches=0, t0=None, dt=0.0,
+                 last_stats={}, printed=False, results=None)
+    metric, workload_name, kernel_name = wl.names()
+
+    def build_line(h, final):
+        """The JSON line for the steps completed so far (cross-rank reductions only when `final`)."""
+        sd = max(state["steps_done"], 1)
+        dt = state["dt"]
+        pc, nn, st = state["results"]     # table of the last completed step (never read while a plan is running)
+        if final:
+            tmax = sharding.reduce_max(dist, dt, cuda)
+            tot_eu, tot_er, tot_it = sharding.reduce_sum_int(dist, [state["eu"], state["er"], state["iters"]], cuda)
+            all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda,
+                                                             device_table=None if a.dry_run else h)
+        else:
+            tmax, tot_eu, tot_er, tot_it = dt, state["eu"], state["er"], state["iters"]
+            all_pc, all_nn, all_st = np.asarray(pc), np.asarray(nn), np.asarray(st)
+        if rank != 0:
+            return None
+        kms, alg, alg2 = state["kernel_ms"], state["alg"], state["alg2"]
+        c4 = a.workload == "c4"
+        found = ((all_st & 2) != 0) if c4 else np.isfinite(all_pc)
+        edges = tot_eu
+        value = edges / tmax if tmax > 0 else None
+        achieved = (alg / 1e9) / (kms / 1e3) if kms > 0 and alg > 0 else None
+        achieved_2s = (alg2 / 1e9) / (kms / 1e3) if kms > 0 and alg2 > 0 else None
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None, "traffic_frac": None,
+                "kernel": kernel_name, "launches": state["launches"],
+                "kernel_ms_per_step": kms / sd, "kernel_ms_per_launch": kms / max(state["launches"], 1),
+                "algorithmic_bytes_per_step": alg / sd,
+                "note": "achieved = bytes the algorithm as implemented must move (rrtx_stats.algorithmic_bytes, "
+                        "accumulated on the device; DESIGN.md 5.1) / HIP-event time of the planner-kernel launches on "
+                        "the handle's stream, measured in this run"}
+        if achieved_2s:
+            roof["survey_8d_two_scan_equivalent_GBps"] = achieved_2s
+            roof["survey_8d_two_scan_note"] = ("SURVEY 8(d)'s two-f64-scan formula (32*n + 48*k + 24*M + 28 per "
+                                               "iteration) applied to the same run: an EQUIVALENT rate, not bytes moved")
+        # HBM traffic from separate rocprofv3 --pmc passes of this exact device code (tools/profile_headline.sh writes
+        # profiles/r2_*_traffic.json with the hash of csrc/ it measured)
+        tfile = os.path.join(ROOT, "profiles", "r2_%s_traffic.json" % a.workload)
+        try:
+            tj = json.load(open(tfile))
+            tc = tj["config"]
+            if tc["instances_per_gpu"] == wl.B and tc["max_iter"] == wl.max_iter and tc["obstacles"] == wl.M:
+                if tj.get("csrc_hash") == csrc_hash():
+                    roof["traffic"] = tj["hbm_bytes_per_launch"]
+                    roof["traffic_per_step"] = tj["hbm_bytes_per_step"]
+                    t_gbps = tj["hbm_bytes_per_step"] / 1e9 / (kms / 1e3 / sd)
+                    roof["traffic_GBps"] = t_gbps
+                    roof["traffic_frac"] = t_gbps / HBM_PEAK_GBPS
+                    roof["traffic_note"] = ("HBM bytes per kernel launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                            "passes of this device code (%s, commit %s); traffic_frac = those bytes / "
+                                            "this run's kernel time / peak" % (os.path.basename(tfile), tj.get("commit")))
+                else:
+                    roof["traffic_note"] = "profiles/%s was measured on other device code (hash %s != %s): not used" % (
+                        os.path.basename(tfile), tj.get("csrc_hash"), csrc_hash())
+        except (OSError, ValueError, KeyError):
+            pass
+        vfile = os.path.join(ROOT, "profiles", "r2_%s_valu.json" % a.workload)
+        try:
+            vj = json.load(open(vfile))
+            if vj.get("csrc_hash") == csrc_hash():
+                roof["valu"] = {k: vj[k] for k in ("valu_busy_frac", "valu_insts_per_launch", "f64_valu_note", "commit")
+                                if k in vj}
+        except (OSError, ValueError, KeyError):
+            pass
+        line = {
+            "metric": metric, "value": value, "unit": "edge expansions/s", "n_gpus": ngpu,
+            "steps": state["steps_done"], "warmup": a.warmup,
+            "ms_per_step": 1e3 * tmax / sd, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload_name, "instances_per_gpu": wl.B, "max_iter": wl.max_iter,
+                       "obstacles": wl.M, "parallelism": "instances x%d" % ngpu},
+            "edge_expansions_reference_equivalent_per_s": tot_er / tmax if tmax > 0 else None,
+            "iterations_per_s": tot_it / tmax if tmax > 0 else None,
+            "plans_per_s": len(all_pc) * state["steps_done"] / tmax if tmax > 0 else None,
+            "mean_nodes_per_tree": float(np.mean(all_nn)),
+            "final_path_cost_mean": float(np.mean(all_pc[found])) if found.any() else None,
+            "final_path_cost_min": float(np.min(all_pc[found])) if found.any() else None,
+            "paths_found": int(found.sum()), "instances_total": int(len(all_pc)),
+            "instances_with_status_bits": {"overflow": int(((all_st & 4) != 0).sum()),
+                                           "unsupported": int(((all_st & 16) != 0).sum()),
+                                           "ref_raises": int(((all_st & 32) != 0).sum())},
+            "roofline": roof,
+            "steps_requested": a.steps, "warmup_max_iter": a.warmup_max_iter or wl.max_iter,
+            "time_budget_s": a.max_seconds, "elapsed_s": elapsed(), "csrc_hash": csrc_hash(),
+            "value_note": "`value` counts the distinct collision-checked edges the device evaluates; "
+                          "edge_expansions_reference_equivalent_per_s counts check_collision calls as the reference "
+                          "makes them for the same trees (repeated near indices included, SURVEY R6)",
+        }
+        ls = state["last_stats"]
+        for k in ("near_unique_max", "f32_fallbacks", "q16_fallbacks", "exact_rescans"):
+            if k in ls:
+                line[k + "_last_step"] = ls[k]
+        if a.workload in ("c5", "c6"):
+            line["edges_steered_per_iteration"] = tot_eu / max(tot_it, 1)
+            line["value_note"] = ("`value` counts the edges the device steers.  The default build steers only the "
+                                  "candidates that can change the result (DESIGN.md 5.5 / 5.7: same trees, several times "
+                                  "fewer edges); the reference and the CPU baseline steer every near candidate -- compare "
+                                  "plans_per_s / iterations_per_s with the CPU baseline, not the edge rates")
+            roof["note"] += ("; this kernel is f64-VALU / latency bound (closed-form trigonometry per candidate edge), its "
+                             "HBM fraction is low by construction -- see roofline.valu for the issue-side bound")
+        if c4:
+            line["unit"] = "edge expansions/s"
+            roof["note"] += "; BIT* is an instance-parallel sequential search (one wave per instance, state in LDS)"
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        if a.dry_run:
+            line["dry_run"] = True
+            line["value"] = None
+        if not final:
+            line["partial"] = True
+        return line
+
+    holder = {}
+
+    def on_term(signum, frame):
+        # killed from outside (e.g. the driver's time limit): report what has been measured, then go
+        h = holder.get("h")
+        if h is not None and state["steps_done"] > 0 and not state["printed"] and rank == 0 and ngpu == 1:
+            try:
+                print(json.dumps(build_line(h, final=False)), flush=True)
+            except Exception:  # noqa: BLE001
+                pass
+        os._exit(143)
+    signal.signal(signal.SIGTERM, on_term)
+
+    def run_blocking(fn):
+        """Run a blocking ABI call on a worker thread so that this (main) thread keeps serving signals."""
+        box = {}
+
+        def target():
+            try:
+                fn()
+            except BaseException as e:  # noqa: BLE001
+                box["e"] = e
+        t = threading.Thread(target=target, daemon=True)
+        t.start()
+        while t.is_alive():
+            t.join(0.25)
+        return box.get("e")
+
+    def all_ok(err):
+        ok = sharding.all_agree_min(dist, 0 if err is not None else 1, cuda)
+        if not ok:
+            if err is not None:
+                print("bench.py rank %d: %s: %s" % (rank, type(err).__name__, err), file=sys.stderr, flush=True)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(1)
+
+    # ---- handles, warm-up
+    device = local_rank
+    if a.dry_run:
+        h = DryHandle(wl.B, wl.max_iter)
+        hw = h
+    else:
+        h = wl.make_handle(wl.max_iter, device)
+        hw = h
+        if a.warmup_max_iter and a.warmup_max_iter != wl.max_iter:
+            hw = wl.make_handle(a.warmup_max_iter, device)
+    holder["h"] = h
+    warm_done = 0
     for _ in range(a.warmup):
-        hw.plan()
+        tw = time.perf_counter()
+        all_ok(run_blocking(lambda: wl.step(hw) if not a.dry_run else hw.plan()))
+        warm_done += 1
+        tw = time.perf_counter() - tw
+        # a warm-up must leave room for at least one timed step (a full-size warm-up costs as much as one)
+        if not sharding.all_agree_min(dist, 1 if elapsed() + 2.5 * tw <= a.max_seconds else 0, cuda):
+            break
     if hw is not h:
         hw.close()
 
+    # ---- timed region
     sync_all()
-    t0 = time.perf_counter()
-    kernel_ms = 0.0
-    alg_bytes = alg_bytes2 = 0
-    edges_u = edges_r = iters = launches = 0
-    steps_done = 0
+    state["t0"] = time.perf_counter()
     for _ in range(a.steps):
         ts = time.perf_counter()
-        h.plan()                      # blocking: returns after the last kernel of the batch has finished
-        steps_done += 1
+        all_ok(run_blocking(lambda: wl.step(h) if not a.dry_run else h.plan()))
         s = h.get_stats()
-        kernel_ms += s["kernel_ms"]
-        alg_bytes += s["algorithmic_bytes"]
-        alg_bytes2 += s["algorithmic_bytes_two_scan"]
-        edges_u += s["edges_unique"]
-        edges_r += s["edges_ref"]
-        iters += s["iterations"]
-        launches += s["launches"]
+        state["last_stats"] = s
+        state["kernel_ms"] += s["kernel_ms"]
+        state["alg"] += s["algorithmic_bytes"]
+        state["alg2"] += s["algorithmic_bytes_two_scan"]
+        state["eu"] += s["edges_unique"]
+        state["er"] += s["edges_ref"]
+        state["iters"] += s["iterations"]
+        state["launches"] += s["launches"]
+        state["results"] = h.get_results()
+        state["steps_done"] += 1
+        state["dt"] = time.perf_counter() - state["t0"]
+        last = time.perf_counter() - ts
         # time guard (all ranks take the same decision: the slowest rank's clock decides)
-        spent, last = time.perf_counter() - t0, time.perf_counter() - ts
-        go = sharding.all_agree_min(dist, 1 if (spent + last <= a.max_seconds) else 0, cuda)
-        if not go:
+        if not sharding.all_agree_min(dist, 1 if elapsed() + 1.1 * last <= a.max_seconds else 0, cuda):
             break
     sync_all()
-    dt = time.perf_counter() - t0
-    pc, nn, st = h.get_results()
-    stats = h.get_stats()
+    state["dt"] = time.perf_counter() - state["t0"]
+    state["warmup_done"] = warm_done
 
-    # ---- cross-rank: max time, summed work, RCCL gather of the result table (the only data collective)
-    tmax = sharding.reduce_max(dist, dt, cuda)
-    tot_edges_u, tot_edges_r = sharding.reduce_sum_int(dist, [edges_u, edges_r], cuda)
-    all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda)
-
+    line = build_line(h, final=True)
     if rank == 0:
-        finite = np.isfinite(all_pc)
-        value = tot_edges_u / tmax
-        # roofline.achieved = bytes the algorithm as implemented must move (ONE pass over the node arrays per iteration
-        # serves both the near-ball query of iteration i and the nearest query of i+1: 16*n + 48*k + 24*M + 28 per
-        # iteration) / HIP-event time of the planner kernel.  SURVEY.md 8(d) wrote the formula for two separate scans
-        # (32*n + ...): that figure is reported next to it as `survey_8d_two_scan_*`.
-        achieved = (alg_bytes / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
-        achieved_2s = (alg_bytes2 / 1e9) / (kernel_ms / 1e3) if kernel_ms > 0 else 0.0
-        traffic = None
-        traffic_note = None
-        # PMC traffic of the same workload and kernel variant, measured in separate rocprofv3 --pmc passes
-        # (tools/profile_headline.sh -> profiles/*_traffic.json)
-        variant = "f64" if os.environ.get("RRTX_F32", "1") == "0" else (
-            "f32_mirror" if os.environ.get("RRTX_Q16", "1") == "0" else "q16_mirror")
-        for tf in ("r1_q16_traffic.json", "r1_t64_traffic.json", "r1_f32_traffic.json", "r1_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-            except Exception:  # noqa: BLE001
-                continue
-            tc = tj["config"]
-            if tc["instances_per_gpu"] == B and tc["max_iter"] == a.max_iter and tc["obstacles"] == a.obstacles \
-                    and tc.get("variant", "f64") == variant and not (c3 or c5):
-                traffic = tj["hbm_bytes_per_step"] / 1e9 / (kernel_ms / 1e3 / max(steps_done, 1))
-                traffic_note = "HBM bytes/step %.4g from profiles/%s" % (tj["hbm_bytes_per_step"], tf)
-                break
-        line = {
-            # BASELINE.json: "RRT* edge expansions/sec + final path cost, 100k-node tree"; the path cost is reported in
-            # final_path_cost_mean / _min below
-            "metric": "%s edge expansions/sec + final path cost, %s tree (collision-checked edges evaluated on the "
-                      "device, distinct per iteration; %d iterations)"
-                      % ("RRT*-Reeds-Shepp" if c6 else "RRT*-Dubins" if c5 else ("Informed RRT*" if c3 else "RRT*"),
-                         "100k-node" if (not c3 and not c5 and a.max_iter >= 100000) else "%d-iteration" % a.max_iter,
-                         a.max_iter),
-            "value": value, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": steps_done, "warmup": a.warmup,
-            "ms_per_step": 1e3 * tmax / max(steps_done, 1), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("C6: rrt_06 RRT*-Reeds-Shepp, driver constants (%d obstacles, 17x17 area, curvature 2, "
-                                    "step_size 0.1, robot_radius 0.6), max_iter %d, %d instances/GPU (seeds 1..)" if c6 else
-                                    "C5: rrt_05 RRT*-Dubins, driver constants (%d obstacles, 17x17 area, curvature 1), "
-                                    "max_iter %d, %d instances/GPU (seeds 1..)" if c5 else
-                                    "C3: rrt_07 Informed RRT*, Sobol sampler, %d circle obstacles (map_seed 11, radii "
-                                    "U(0.3,1.5)) on 100x100, expand_dis 0.5, max_iter %d, %d instances/GPU (seeds 1..)"
-                                    if c3 else
-                                    "C2: rrt_04 RRT*, %d circle obstacles (map_seed 7) on 100x100, expand_dis 2.0, "
-                                    "path_resolution 0.25, max_iter %d, %d instances/GPU (seeds 1..), MT sampler")
-                                   % (a.obstacles, a.max_iter, B),
-                       "instances_per_gpu": B, "max_iter": a.max_iter, "parallelism": "instances x%d" % ngpu},
-            "edge_expansions_reference_equivalent_per_s": tot_edges_r / tmax,
-            "mean_nodes_per_tree": float(np.mean(all_nn)),
-            "final_path_cost_mean": float(np.mean(all_pc[finite])) if finite.any() else None,
-            "final_path_cost_min": float(np.min(all_pc[finite])) if finite.any() else None,
-            "paths_found": int(finite.sum()), "instances_total": int(len(all_pc)),
-            "iterations_per_s": iters * ngpu / tmax,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": "rppr::rrt_rs_kernel" if c6 else "rppd::rrt_dubins_kernel" if c5 else (
-                             "rppi::rrt_informed_kernel" if c3 else "rppk2(s)::rrt_star_kernel_v2"),
-                         "launches": launches,
-                         "algorithmic_bytes_per_step": alg_bytes / max(steps_done, 1),
-                         "traffic_note": traffic_note,
-                         "survey_8d_two_scan_GBps": achieved_2s, "survey_8d_two_scan_frac": achieved_2s / 8000.0,
-                         "note": "achieved = single-pass algorithmic bytes (4*n per iteration from the 16-bit coordinate mirror, 8*n with RRTX_Q16=0 (f32 mirror), 16*n with RRTX_F32=0: the near pass of "
-                                 "iteration i also answers the nearest query of i+1) / kernel time; "
-                                 "survey_8d_two_scan_* applies SURVEY 8(d)'s two-scan formula (32*n) to the same run",
-                         "kernel_ms_per_step": kernel_ms / max(steps_done, 1)},
-            "steps_requested": a.steps, "warmup_max_iter": a.warmup_max_iter or a.max_iter,
-            "near_unique_max": stats.get("near_unique_max"), "f32_fallbacks_last_step": stats.get("f32_fallbacks"),
-            "q16_fallbacks_last_step": stats.get("q16_fallbacks"),
-            "exact_rescans_last_step": stats.get("exact_rescans"),
-        }
-        if c5 and not c6:
-            line["plans_per_s"] = len(all_pc) * steps_done / tmax
-            line["edges_steered_per_iteration"] = tot_edges_u / max(iters * ngpu, 1)
-            line["value_note"] = ("`value` counts the Dubins edges the device steers.  The default build steers only the "
-                                  "candidates that can change the result (DESIGN.md 5.5, filtered candidate stages: same "
-                                  "trees, ~8x fewer edges); RRTX_DUBINS_FILTER=0 steers every near candidate as the "
-                                  "reference and the CPU baseline do -- compare iterations_per_s / plans_per_s across "
-                                  "builds, not the edge rates")
-        if c6:
-            line["plans_per_s"] = len(all_pc) * steps_done / tmax
-            line["edges_steered_per_iteration"] = tot_edges_u / max(iters * ngpu, 1)
-            line["roofline"]["note"] = (
-                "rrt_06's iteration is closed-form f64 trigonometry (48 Reeds-Shepp word evaluations per steer, glibc-exact "
-                "sin/cos/atan2/acos/asin/pow replicas), not a stream: the kernel is f64-VALU / latency bound and its HBM "
-                "figure (16 B per node and scan + 24 B per polyline point written) is far below the HBM roof by "
-                "construction.  `value` counts the edges the device steers (lazy candidate order, DESIGN.md 5.7); the "
-                "reference and the oracle steer every near candidate (RRTX_RS_EAGER=1 does the same on the device), so "
-                "compare plans_per_s with cpu_baseline.plans_per_s, not the edge rates")
-        if not a.no_cpu_baseline and ngpu == 1:   # the CPU baseline is reported by the single-GPU run only
-            import oracle
-            tc = time.perf_counter()
-            if c6:
-                kc = dict(max_iter=a.max_iter)
-                ncpu = 64
-                r = None
-                eu = er = 0
-                for sd in range(1, ncpu + 1):
-                    r = oracle.plan_rrt_rs(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], a.max_iter, seed=sd,
-                                           curvature=2.0, robot_radius=0.6, step_size=0.1)
-                    eu += r["stats"]["edges_unique"]
-                    er += r["stats"]["edges_ref"]
-                r["stats"]["edges_unique"], r["stats"]["edges_ref"] = eu, er
-            elif c5:
-                kc = dict(max_iter=min(a.cpu_iters, a.max_iter))
-                r = oracle.plan_dubins(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], kc["max_iter"], seed=1)
-            elif c3:
-                kc = dict(kw)
-                kc.pop("algo")
-                kc["max_iter"] = min(a.cpu_iters, a.max_iter)
-                r = oracle.plan_informed(seed=1, exact_pow=False, **kc)
-            else:
-                kc = util.c2_kwargs(a.cpu_iters, m=a.obstacles)
-                r = oracle.plan(seed=1, exact_pow=False, **kc)
-            tc = time.perf_counter() - tc
-            if c6:
-                line["cpu_baseline"] = {"value": r["stats"]["edges_unique"] / tc, "unit": "edge expansions/s", "cores": 1,
-                                        "kind": "port", "plans_per_s": ncpu / tc,
-                                        "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference), the first %d "
-                                                  "instances (seeds 1..%d) of the same workload one after the other, %.1f s; "
-                                                  "every near candidate steered as the reference does"
-                                                  % (ncpu, ncpu, tc)}
-                print(json.dumps(line), flush=True)
-                h.close()
-                if dist is not None:
-                    dist.barrier()
-                    dist.destroy_process_group()
-                return
-            line["cpu_baseline"] = {"value": r["stats"]["edges_unique"] / tc, "unit": "edge expansions/s", "cores": 1,
-                                    "kind": "port",
-                                    "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference), 1 instance, "
-                                              "seed 1, %d iterations (%d nodes) of the same workload, %.1f s; "
-                                              "reference-equivalent rate %.0f/s"
-                                              % (kc["max_iter"], len(r["x"]), tc, r["stats"]["edges_ref"] / tc)}
+        line["warmup"] = warm_done
+        state["printed"] = True
         print(json.dumps(line), flush=True)
     h.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def bench_c4(a, A, sharding, rrt_amd, dist, torch, rank, local_rank, ngpu):
-    """C4: rrt_08 BIT*, driver constants (rrt_08:633-665); instance i has start/goal drawn from
-    random.Random(2000+i) in [-1,14]^2 outside the obstacles and planner seed 1000+i; rank r owns instances
-    r*B .. (r+1)*B-1.  One step = every instance planned (maxIter 80).  Unit of work: edges popped from the edge queue."""
-    import random
-    import numpy as np
-    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
-    B = a.instances if "--instances" in sys.argv else 4096
-    max_iter = a.max_iter if "--max-iter" in sys.argv else 80
-    cuda = torch.device("cuda", local_rank) if dist is not None else None
-
-    def free_point(rng):
-        while True:
-            x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
-            if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
-                return [x, y]
-    starts, goals, seeds = [], [], []
-    for i in range(rank * B, (rank + 1) * B):
-        rng = random.Random(2000 + i)
-        starts.append(free_point(rng))
-        goals.append(free_point(rng))
-        seeds.append(1000 + i)
-    c_min, c = rrt_amd.bitstar_rotation(starts[0], goals[0])
-    h = A.Handle(A.ALGO_BITSTAR, starts[0], goals[0], [-2.0, 15.0], 2.0, 1.0, 0, max_iter, n_instances=B,
-                 device=local_rank, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
-    h.set_obstacles(obst)
-    h.seed_instances(seeds)
-    for i in range(B):
-        cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])   # numpy SVD on the host, as the reference does
-        h.set_instance(i, starts[i], goals[i])
-        h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
-    def plan_tolerant():
-        # an instance whose start is walled in keeps drawing sample batches without bound (the reference would too);
-        # it ends with RRTX_E_OVERFLOW in its status word and is reported below, the other instances are unaffected
-        try:
-            h.plan()
-        except A.RrtxError as e:
-            if "OVERFLOW" not in str(e):
-                raise
-
-    for _ in range(a.warmup):
-        h.seed_instances(seeds)
-        plan_tolerant()
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kernel_ms = 0.0
-    edges = 0
-    for _ in range(a.steps):
-        h.seed_instances(seeds)
-        plan_tolerant()
-        s = h.get_stats()
-        kernel_ms += s["kernel_ms"]
-        edges += s["edges_unique"]
-    if dist is not None:
-        dist.barrier()
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    pc, nn, st = h.get_results()
-    tmax = sharding.reduce_max(dist, dt, cuda)
-    (tot_edges,) = sharding.reduce_sum_int(dist, [edges], cuda)
-    all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda)
-    if rank == 0:
-        found = (all_st & 2) != 0
-        line = {"metric": "BIT* edge-queue expansions/sec (edges popped and processed, rrt_08:262-318), %d-iteration plans"
-                          % max_iter,
-                "value": tot_edges / tmax, "unit": "edge expansions/s", "n_gpus": ngpu, "steps": a.steps,
-                "warmup": a.warmup, "ms_per_step": 1e3 * tmax / max(a.steps, 1), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "C4: rrt_08 BIT*, driver constants (6 obstacles, rand_area [-2,15], maxIter %d), "
-                                       "per-instance start/goal from random.Random(2000+i), planner seed 1000+i, "
-                                       "%d instances/GPU" % (max_iter, B),
-                           "instances_per_gpu": B, "max_iter": max_iter, "parallelism": "instances x%d" % ngpu},
-                "plans_per_s": B * ngpu * a.steps / tmax, "paths_found": int(found.sum()),
-                "instances_capacity_exceeded": int(((all_st & 4) != 0).sum()),
-                "instances_total": int(len(all_pc)), "mean_vertices_per_tree": float(np.mean(all_nn)),
-                "roofline": {"bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None,
-                             "traffic": None, "kernel": "rppb::bitstar_kernel",
-                             "note": "instance-parallel sequential search (one lane per instance): latency-bound, "
-                                     "no streaming pass to price against HBM",
-                             "kernel_ms_per_step": kernel_ms / max(a.steps, 1)}}
-        if not a.no_cpu_baseline and ngpu == 1:
-            import oracle
-            nsmp = min(B, 48)
-            tc = time.perf_counter()
-            ce = 0
-            for i in range(nsmp):
-                r = oracle.plan_bitstar(starts[i], goals[i], obst, [-2, 15], max_iter, seed=seeds[i])
-                ce += int(r.get("n_trace", 0)) if isinstance(r, dict) else 0
-            tc = time.perf_counter() - tc
-            line["cpu_baseline"] = {"value": nsmp / tc, "unit": "plans/s", "cores": 1, "kind": "port",
-                                    "sample": "oracle/rrt_oracle.c, the first %d instances of the same workload, %.1f s "
-                                              "(compare with plans_per_s)" % (nsmp, tc)}
-        print(json.dumps(line), flush=True)
-    h.close()
 
 
 if __name__ == "__main__":

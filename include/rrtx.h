@@ -25,16 +25,21 @@
 extern "C" {
 #endif
 
-#define RRTX_ABI_VERSION 2   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw */
+#define RRTX_ABI_VERSION 3   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
+                                rrtx_copy_results_device, per-instance yaw and informed rotation */
 
 enum {
+  RRTX_PARTIAL = 1,        /* rrtx_plan only: the call completed, but at least one instance stopped with RRTX_ST_OVERFLOW,
+                              RRTX_ST_UNSUPPORTED or RRTX_ST_REF_RAISES in its status word (rrtx_get_results); every
+                              other instance is complete and valid.  Not an error: errors are negative. */
   RRTX_OK = 0,
   RRTX_E_INVALID = -1,     /* bad argument / unsupported parameter combination */
   RRTX_E_NO_DEVICE = -2,   /* no HIP device, or not gfx950 */
   RRTX_E_HIP = -3,         /* HIP runtime error, see rrtx_last_error */
   RRTX_E_CAPACITY = -4,    /* caller buffer too small */
   RRTX_E_STATE = -5,       /* call order (e.g. get_tree before plan) */
-  RRTX_E_OVERFLOW = -6     /* an on-device work list exceeded its fixed capacity; result invalid */
+  RRTX_E_OVERFLOW = -6     /* a whole-call capacity was exceeded (path smoothing); per-instance overflows of rrtx_plan are
+                              reported as RRTX_PARTIAL + RRTX_ST_OVERFLOW */
 };
 
 enum { RRTX_ALGO_RRT = 0,       /* rrt_01 RRT.planning :71-101 */
@@ -127,13 +132,16 @@ int rrtx_set_rng_state(rrtx_handle* h, int32_t instance, const uint32_t* mt624, 
 int rrtx_get_rng_state(rrtx_handle* h, int32_t instance, uint32_t* mt624, int32_t* pos);
 /* convenience: state after `random.seed(seed)` for instances first..first+count-1 */
 int rrtx_seed_instances(rrtx_handle* h, int32_t first, int32_t count, const uint64_t* seeds);
-/* per-instance start / goal for batches (default: the ctor's).  The pose planners (RRTX_ALGO_DUBINS / _RRT_DUBINS / _RS)
- * take x, y per instance; start and goal yaw are the ctor's for every instance of a handle. */
+/* per-instance start / goal for batches (default: the ctor's): x, y and, for the pose planners (RRTX_ALGO_DUBINS /
+ * _RRT_DUBINS / _RS), yaw in element 2 (rrt_05:1406-1407, rrt_06:1518-1519).  Either pointer may be NULL. */
 int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, const double* goal3);
-/* RRTX_ALGO_BITSTAR: per-instance rotation `C` (upper-left 2x2, row major) and cMin = hypot(start-goal)/1.5, computed
- * by the host with numpy exactly as rrt_08:189-202 does (default: the ctor's informed_rot / informed_c_min). */
+/* Per-instance rotation `C` (upper-left 2x2, row major) and c_min, computed by the host with numpy exactly as the
+ * reference does for that instance's start / goal (default: the ctor's informed_rot / informed_c_min):
+ * RRTX_ALGO_BITSTAR cMin = hypot(start-goal)/1.5 and C of rrt_08:189-202; RRTX_ALGO_INFORMED c_min = hypot(start-goal)
+ * and C of rrt_07:1054-1068 (the ellipse centre follows rrtx_set_instance). */
 int rrtx_set_instance_rotation(rrtx_handle* h, int32_t instance, const double* rot4, double c_min);
-/* replaces the body of RRT.planning(animation=False) for every instance; blocking. */
+/* replaces the body of RRT.planning(animation=False) for every instance; blocking.  Returns RRTX_OK, RRTX_PARTIAL
+ * (see above) or a negative error. */
 int rrtx_plan(rrtx_handle* h);
 /* rrt.node_list as SoA: x, y, cost (f64), parent (i32, -1 = None); any pointer may be NULL. */
 int rrtx_get_tree(rrtx_handle* h, int32_t instance, double* x, double* y, double* cost, int32_t* parent,
@@ -145,6 +153,9 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
 int rrtx_get_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status);
 /* device pointer + byte size of the packed result table (n_instances x {f64 cost, i32 n, i32 status}) */
 int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes);
+/* the same table copied device -> device into a caller-owned device buffer (e.g. the tensor an RCCL all_gather sends):
+ * no round trip through host memory; `bytes` = capacity of dst_device (>= 16 * n_instances) */
+int rrtx_copy_results_device(rrtx_handle* h, void* dst_device, int64_t bytes);
 /* RRTX_ALGO_DUBINS: node yaw (rrt_05 Node.yaw) and the stored edge polylines (Node.path_x / path_y, :1472-1474):
  * plen[i] points per node, concatenated in node order into px/py. */
 int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap);

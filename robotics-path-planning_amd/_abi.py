@@ -12,16 +12,18 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
-RRTX_ABI_VERSION = 2
+RRTX_ABI_VERSION = 3
 ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR, ALGO_RRT_DUBINS, ALGO_RS = 0, 1, 2, 3, 4, 5, 6
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
-ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC = 1, 2, 4, 8
-ERRORS = {0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
+ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC, ST_UNSUPPORTED, ST_REF_RAISES = 1, 2, 4, 8, 16, 32
+ST_FAILED = ST_OVERFLOW | ST_UNSUPPORTED | ST_REF_RAISES   # the instance stopped without a result
+RRTX_PARTIAL = 1
+ERRORS = {1: "RRTX_PARTIAL", 0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
           -5: "RRTX_E_STATE", -6: "RRTX_E_OVERFLOW"}
 
 EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
-           "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
+           "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_copy_results_device", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
            "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw"]
 
@@ -81,6 +83,7 @@ def load():
     L.rrtx_get_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.rrtx_get_results.argtypes = [vp, vp, vp, vp]
     L.rrtx_results_device_ptr.argtypes = [vp, C.POINTER(vp), i64p]
+    L.rrtx_copy_results_device.argtypes = [vp, vp, C.c_int64]
     L.rrtx_get_sobol_index.argtypes = [vp, i32, i64p]
     L.rrtx_get_yaw.argtypes = [vp, i32, vp, i32]
     L.rrtx_get_polylines.argtypes = [vp, i32, vp, i32, vp, vp, C.c_int64, i64p]
@@ -151,7 +154,7 @@ class Handle:
             raise RrtxError("rrtx_create: %s %s" % (ERRORS.get(rc, rc), msg))
 
     def _chk(self, rc, what):
-        if rc != 0:
+        if rc < 0:
             raise RrtxError("%s: %s %s" % (what, ERRORS.get(rc, rc), self.L.rrtx_last_error(self._h).decode()))
 
     def close(self):
@@ -187,8 +190,12 @@ class Handle:
         self._chk(self.L.rrtx_seed_instances(self._h, first, len(s), s.ctypes.data), "rrtx_seed_instances")
 
     def set_instance(self, instance, start=None, goal=None):
-        s = (C.c_double * 3)(*([float(v) for v in start] + [0.0] * (3 - len(start)))) if start is not None else None
-        g = (C.c_double * 3)(*([float(v) for v in goal] + [0.0] * (3 - len(goal)))) if goal is not None else None
+        """Per-instance start / goal: [x, y] or, for the pose planners, [x, y, yaw] (a missing yaw keeps the ctor's)."""
+        def vec(v, dflt):
+            w = [float(q) for q in v]
+            return (C.c_double * 3)(*(w + [float(dflt[i]) for i in range(len(w), 3)]))
+        s = vec(start, self.params.start) if start is not None else None
+        g = vec(goal, self.params.goal) if goal is not None else None
         self._chk(self.L.rrtx_set_instance(self._h, instance, C.cast(s, C.c_void_p) if s else None,
                                            C.cast(g, C.c_void_p) if g else None), "rrtx_set_instance")
 
@@ -200,8 +207,18 @@ class Handle:
     def enable_trace(self, instance):
         self._chk(self.L.rrtx_enable_trace(self._h, instance), "rrtx_enable_trace")
 
-    def plan(self):
-        self._chk(self.L.rrtx_plan(self._h), "rrtx_plan")
+    def plan(self, strict=False):
+        """Returns 0, or RRTX_PARTIAL when some instances stopped with a status bit of ST_FAILED (the other instances
+        are complete; see get_results / last_error).  Raises for errors only -- and, with strict=True (what the
+        single-instance drop-in classes use), for RRTX_PARTIAL as well."""
+        rc = self.L.rrtx_plan(self._h)
+        self._chk(rc, "rrtx_plan")
+        if rc == RRTX_PARTIAL and strict:
+            raise RrtxError("rrtx_plan: %s" % self.last_error())
+        return rc
+
+    def last_error(self):
+        return self.L.rrtx_last_error(self._h).decode()
 
     def get_tree(self, instance=0):
         n = C.c_int32()
@@ -242,6 +259,11 @@ class Handle:
         p = C.c_void_p(); b = C.c_int64()
         self._chk(self.L.rrtx_results_device_ptr(self._h, C.byref(p), C.byref(b)), "rrtx_results_device_ptr")
         return p.value, b.value
+
+    def copy_results_device(self, dst_device_ptr, nbytes):
+        """Result table device -> device (dst = e.g. torch tensor .data_ptr() on this handle's device)."""
+        self._chk(self.L.rrtx_copy_results_device(self._h, C.c_void_p(int(dst_device_ptr)), int(nbytes)),
+                  "rrtx_copy_results_device")
 
     def get_yaw(self, instance=0):
         n = C.c_int32()

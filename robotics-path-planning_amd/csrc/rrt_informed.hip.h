@@ -146,16 +146,18 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
   }
 }
 
-// rot: C[0][0], C[0][1], C[1][0], C[1][1]; xc: ellipse centre; c_min2 = c_min**2 (host libm)
+// per instance -- rot: C[0][0], C[0][1], C[1][0], C[1][1]; xc: ellipse centre; c_min2 = c_min**2 (host libm)
 struct InformedArgs {
   double rot[4];
   double xc[2];
   double c_min2;
 };
 
-__global__ __launch_bounds__(TPB, 4) void rrt_informed_kernel(Ctx c, InformedArgs ia, double* cbest_io, int iters) {
+__global__ __launch_bounds__(TPB, 4) void rrt_informed_kernel(Ctx c, const InformedArgs* __restrict__ per_inst,
+                                                              double* cbest_io, int iters) {
   __shared__ ShI sh;
   const int inst = blockIdx.x;
+  const InformedArgs ia = per_inst[inst];   // rotation, centre and c_min**2 of THIS instance's start / goal pair
   const int tid = threadIdx.x;
   Inst* I = c.inst + inst;
   if (I->status & 1) return;

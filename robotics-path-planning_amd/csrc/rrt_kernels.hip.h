@@ -55,7 +55,7 @@ struct Result {  // 16 B record gathered across GPUs
 struct Inst {  // persistent per-instance state (global memory)
   rpp::MT rng;
   rpp::Sobol sobol;
-  double start[2], goal[2];
+  double start[3], goal[3];   // x, y and (pose planners: rrt_03 / rrt_05 / rrt_06) yaw of this instance
   int32_t n, it, status, goal_node, path_n;
   int32_t first_goal;   // lowest index of a node lying exactly on the goal (-1 none yet, -2 unknown); f32-mirror path only
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
@@ -93,7 +93,7 @@ struct Ctx {
   // f32 mirror of x[], y[] (prefilter of the streaming pass, rrt_star_v2_body.inc) and its distance margin
   float *xf, *yf;
   double f32_m;
-  // 16-bit fixed-point mirror, 4 bytes per node: (x16 | y16 << 16), q = rint((coord - q_lo) * q_inv); first stage of
+  // 16-bit fixed-point mirror, 4 bytes per node: (x16 | y16 << 16), q = rint((coord - q_lo) * q_inv) - 32768; first stage of
   // the rrt_04 iteration kernel's streaming pass (scan2q); q_m = distance margin of that stage
   uint32_t* xq;
   double q_lo, q_inv, q_step, q_m;
@@ -107,7 +107,7 @@ __device__ __forceinline__ uint32_t quant16(const Ctx& c, double px, double py) 
   double qx = __builtin_rint((px - c.q_lo) * c.q_inv), qy = __builtin_rint((py - c.q_lo) * c.q_inv);
   qx = qx < 0.0 ? 0.0 : (qx > 65535.0 ? 65535.0 : qx);
   qy = qy < 0.0 ? 0.0 : (qy > 65535.0 ? 65535.0 : qy);
-  return (uint32_t)qx | ((uint32_t)qy << 16);
+  return ((uint32_t)qx | ((uint32_t)qy << 16)) ^ 0x80008000u;   // each half as a signed 16-bit value: q - 32768
 }
 
 struct Sh {

@@ -251,9 +251,9 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
   __syncthreads();
   int n = I->n, it = I->it;
   int64_t pool_used = da.pool_used[inst];
-  const double gx = I->goal[0], gy = I->goal[1];
+  const double gx = I->goal[0], gy = I->goal[1], gyaw = I->goal[2];
   if (it == 0 && lane == 0) {
-    yaw[0] = da.start_yaw;
+    yaw[0] = I->start[2];
     poff[0] = 0;
     plen[0] = 0;
   }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     double best = rpp::dinf();
     int bidx = 0x7fffffff;
     for (int i = lane; i < n; i += TPB) {
-      if (rpp::py_hypot(x[i] - gx, y[i] - gy) <= da.goal_xy_th && rpp::dabs(yaw[i] - da.goal_yaw) <= da.goal_yaw_th) {
+      if (rpp::py_hypot(x[i] - gx, y[i] - gy) <= da.goal_xy_th && rpp::dabs(yaw[i] - gyaw) <= da.goal_yaw_th) {
         const double cc = cost[i];
         if (cc < best) {
           best = cc;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
         if (stop) break;
         // ---------------- try_goal_path :1572-1582
         int gc = 0, gn = 0;
-        const int gk = rs_edge(da, m, sh, x[me], y[me], yaw[me], gx, gy, da.goal_yaw, pool_x + pool_used,
+        const int gk = rs_edge(da, m, sh, x[me], y[me], yaw[me], gx, gy, gyaw, pool_x + pool_used,
                                pool_y + pool_used, pool_w + pool_used, da.pool_cap - pool_used, &gc, &gn);
         if (fatal(gk)) break;
         s_e += gk ? 1 : 0;

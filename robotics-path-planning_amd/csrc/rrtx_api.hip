@@ -59,7 +59,11 @@ struct rrtx_handle {
   std::string err;
   std::vector<void*> allocs;
   int chunk_iters = 1024;
+  int v2_chunk_iters = 16384;   // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
+  std::vector<rppi::InformedArgs> iargs;   // informed RRT*: per-instance rotation C / c_min**2 (centre filled at plan time)
+  std::vector<double> icmin;               // informed RRT*: per-instance c_min as handed in
+  rppi::InformedArgs* d_iargs = nullptr;
   rppd::DubArgs da;         // RRT*-Dubins device arrays
   rppb::BitArgs ba;         // BIT* device arrays
   std::vector<rpp::BitCfg> bcfg;
@@ -139,7 +143,13 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   h->n_inst = p->n_instances;
   memset(&h->stats, 0, sizeof(h->stats));
   memset(&h->c, 0, sizeof(h->c));
-  if (const char* e = getenv("RRTX_CHUNK_ITERS")) h->chunk_iters = atoi(e) > 0 ? atoi(e) : 1024;
+  // Iterations per kernel launch.  A launch ends when its slowest instance does, so short chunks leave the chip
+  // part idle at the end of every launch: 1024-iteration chunks cost the C2 batch 9 % (103 launches) against one launch;
+  // 16384 keeps that under 2 % and still returns to the host every few seconds.
+  if (const char* e = getenv("RRTX_CHUNK_ITERS")) {
+    h->chunk_iters = atoi(e) > 0 ? atoi(e) : 1024;
+    h->v2_chunk_iters = h->chunk_iters;
+  }
   *out = h;  // returned even on failure below so the caller can read last_error, then destroy
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -212,6 +222,13 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   }
   if (p->algo == RRTX_ALGO_INFORMED) {
     if ((rc = dalloc(h, &h->cbest, h->n_inst))) return rc;
+    if ((rc = dalloc(h, &h->d_iargs, h->n_inst))) return rc;
+    h->iargs.resize(h->n_inst);
+    h->icmin.assign(h->n_inst, p->informed_c_min);
+    for (int i = 0; i < h->n_inst; i++) {
+      for (int k = 0; k < 4; k++) h->iargs[i].rot[k] = p->informed_rot[k];
+      h->iargs[i].c_min2 = py_sq_host(p->informed_c_min);   // c_min ** 2 rrt_07:1147
+    }
   }
   memset(&h->ba, 0, sizeof(h->ba));
   if (p->algo == RRTX_ALGO_BITSTAR) {
@@ -252,8 +269,6 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     d.curvature = p->curvature;
     d.goal_yaw_th = p->goal_yaw_th;
     d.goal_xy_th = p->goal_xy_th;
-    d.start_yaw = p->start[2];
-    d.goal_yaw = p->goal[2];
   }
   if (p->algo == RRTX_ALGO_RS) {
     rppd::DubArgs& d = h->da;
@@ -275,10 +290,10 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     Inst& I = h->host_inst[i];
     memset(&I, 0, sizeof(I));
     rpp::mt_seed_u64(&I.rng, (uint64_t)i);
-    I.start[0] = p->start[0];
-    I.start[1] = p->start[1];
-    I.goal[0] = p->goal[0];
-    I.goal[1] = p->goal[1];
+    for (int k = 0; k < 3; k++) {
+      I.start[k] = p->start[k];
+      I.goal[k] = p->goal[k];
+    }
   }
   return RRTX_OK;
 }
@@ -343,6 +358,7 @@ int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, co
   if (start3) {
     I.start[0] = start3[0];
     I.start[1] = start3[1];
+    if (is_pose_tree(h->p.algo)) I.start[2] = start3[2];   // yaw (rrt_05:1406, rrt_06:1518)
     if (h->p.algo == RRTX_ALGO_BITSTAR) {
       h->bcfg[instance].start[0] = start3[0];
       h->bcfg[instance].start[1] = start3[1];
@@ -351,6 +367,7 @@ int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, co
   if (goal3) {
     I.goal[0] = goal3[0];
     I.goal[1] = goal3[1];
+    if (is_pose_tree(h->p.algo)) I.goal[2] = goal3[2];
     if (h->p.algo == RRTX_ALGO_BITSTAR) {
       h->bcfg[instance].goal[0] = goal3[0];
       h->bcfg[instance].goal[1] = goal3[1];
@@ -361,6 +378,12 @@ int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, co
 
 int rrtx_set_instance_rotation(rrtx_handle* h, int32_t instance, const double* rot4, double c_min) {
   if (!h || !rot4 || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  if (h->p.algo == RRTX_ALGO_INFORMED) {
+    for (int k = 0; k < 4; k++) h->iargs[instance].rot[k] = rot4[k];
+    h->iargs[instance].c_min2 = py_sq_host(c_min);   // c_min ** 2 rrt_07:1147
+    h->icmin[instance] = c_min;
+    return RRTX_OK;
+  }
   if (h->p.algo != RRTX_ALGO_BITSTAR) return RRTX_E_STATE;
   rpp::BitCfg& c2 = h->bcfg[instance];
   for (int k = 0; k < 4; k++) c2.rot[k] = rot4[k];
@@ -404,8 +427,8 @@ int rrtx_plan(rrtx_handle* h) {
     if (c.algo == RRTX_ALGO_INFORMED) mag *= 2.0;
     c.f32_m = ldexp(mag > 1.0 ? mag : 1.0, -20);
     // 16-bit mirror: the square [lo, hi]^2 that holds every node and sample (sampling square, starts, goals; nodes are
-    // convex combinations of those).  Quantisation error <= step/2 per coordinate -> distance error <= step/sqrt(2)
-    // (+ f32 arithmetic ~1e-5 * range); margin = one step.
+    // convex combinations of those).  Quantisation error <= step/2 per coordinate -> a point moves by <= step/sqrt(2);
+    // node and query are both on the grid -> distance error < sqrt(2) steps; the arithmetic is exact (integer).
     double lo = c.rand_min < c.rand_max ? c.rand_min : c.rand_max, hi = c.rand_min < c.rand_max ? c.rand_max : c.rand_min;
     for (int i = 0; i < B; i++) {
       const Inst& I = h->host_inst[i];
@@ -419,7 +442,7 @@ int rrtx_plan(rrtx_handle* h) {
     c.q_lo = lo;
     c.q_step = range / 65535.0;
     c.q_inv = 65535.0 / range;
-    c.q_m = c.q_step;
+    c.q_m = 1.4375 * c.q_step;   // node AND query rounded to the grid: sqrt(2) steps (scan2q)
   }
   if (const char* e = getenv("RRTX_F32"))
     if (atoi(e) == 0 && c.algo == RRTX_ALGO_INFORMED) c.xf = c.yf = nullptr;   // informed kernel: f64 passes only
@@ -485,23 +508,23 @@ int rrtx_plan(rrtx_handle* h) {
     // magnitude any node or sample can have (see scan2f)
     bool f32 = c.xf != nullptr;
     if (const char* e = getenv("RRTX_F32")) f32 = f32 && atoi(e) != 0;
-    for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->chunk_iters) {
+    for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->v2_chunk_iters) {
       HIPCHK(h, hipEventRecord(h->ev0, h->stream));
       if (tpb == 64) {
         if (f32)
-          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->chunk_iters);
+          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->v2_chunk_iters);
         else
-          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->chunk_iters);
+          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->v2_chunk_iters);
       } else if (tpb == 128) {
         if (f32)
-          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
+          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->v2_chunk_iters);
         else
-          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->chunk_iters);
+          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->v2_chunk_iters);
       } else {
         if (f32)
-          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->chunk_iters);
+          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->v2_chunk_iters);
         else
-          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->chunk_iters);
+          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->v2_chunk_iters);
       }
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipEventRecord(h->ev1, h->stream));
@@ -524,15 +547,18 @@ int rrtx_plan(rrtx_handle* h) {
   h->da.filter = 1;
   if (const char* e = getenv("RRTX_DUBINS_FILTER")) h->da.filter = atoi(e) != 0;
   if (const char* e = getenv("RRTX_DUBINS_LAZY")) h->da.lazy = atoi(e) != 0;
-  rppi::InformedArgs ia;
-  for (int i = 0; i < 4; i++) ia.rot[i] = h->p.informed_rot[i];
-  ia.xc[0] = (h->p.start[0] + h->p.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
-  ia.xc[1] = (h->p.start[1] + h->p.goal[1]) / 2.0;
-  ia.c_min2 = py_sq_host(h->p.informed_c_min);       // c_min ** 2 rrt_07:1147
+  if (c.algo == RRTX_ALGO_INFORMED) {
+    for (int i = 0; i < B; i++) {
+      const Inst& I = h->host_inst[i];
+      h->iargs[i].xc[0] = (I.start[0] + I.goal[0]) / 2.0;   // x_center rrt_07:1056-1057
+      h->iargs[i].xc[1] = (I.start[1] + I.goal[1]) / 2.0;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_iargs, h->iargs.data(), sizeof(rppi::InformedArgs) * B, hipMemcpyHostToDevice, h->stream));
+  }
   for (;;) {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (c.algo == RRTX_ALGO_INFORMED)
-      hipLaunchKernelGGL(rppi::rrt_informed_kernel, dim3(B), dim3(rppi::TPB), 0, h->stream, c, ia, h->cbest,
+      hipLaunchKernelGGL(rppi::rrt_informed_kernel, dim3(B), dim3(rppi::TPB), 0, h->stream, c, h->d_iargs, h->cbest,
                          h->chunk_iters);
     else if (is_dubins(c.algo))
       hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(B), dim3(rppd::TPB), 0, h->stream, c, h->da, h->chunk_iters);
@@ -593,19 +619,19 @@ int rrtx_plan(rrtx_handle* h) {
   s.kernel_ms = kms;
   s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   h->planned = true;
-  if (overflow) {
-    h->err = "a fixed on-device capacity was exceeded (near-candidate list NU_MAX, polyline pool, or a BIT* slab)";
-    return RRTX_E_OVERFLOW;
-  }
-  if (raises) {
-    h->err = "rrt_06: the reference raises inside reeds_shepp_path_planning for at least one instance (status bit "
-             "RRTX_ST_REF_RAISES; ZeroDivisionError :1183/:1207 or a math domain error); those instances have no result";
-    return RRTX_E_STATE;
-  }
-  if (unsupported) {
-    h->err = "rrt_04 rewire: a node moved by an unsnapped steer is listed again in near_inds (distance tie); the "
-             "reference's second visit is not restated on the device";
-    return RRTX_E_STATE;
+  // Per-instance conditions are per-instance results: the status word of each instance carries them
+  // (rrtx_get_results), the other instances' trees are complete and valid.
+  if (overflow || raises || unsupported) {
+    h->err.clear();
+    if (overflow)
+      h->err += "RRTX_ST_OVERFLOW: a fixed on-device capacity was exceeded (near-candidate list, polyline pool, or a "
+                "BIT* slab); ";
+    if (raises)
+      h->err += "RRTX_ST_REF_RAISES: the reference raises inside reeds_shepp_path_planning (ZeroDivisionError "
+                "rrt_06:1183/:1207 or a math domain error); ";
+    if (unsupported) h->err += "RRTX_ST_UNSUPPORTED: a reference code path the kernel does not restate was reached; ";
+    h->err += "the affected instances carry the bit in their status word and have no result, all others are complete";
+    return RRTX_PARTIAL;
   }
   return RRTX_OK;
 }
@@ -759,6 +785,16 @@ int rrtx_results_device_ptr(rrtx_handle* h, void** dptr, int64_t* bytes) {
   return RRTX_OK;
 }
 
+int rrtx_copy_results_device(rrtx_handle* h, void* dst_device, int64_t bytes) {
+  if (!h || !dst_device) return RRTX_E_INVALID;
+  if (!h->planned) return RRTX_E_STATE;
+  if (bytes < (int64_t)sizeof(Result) * h->n_inst) return RRTX_E_CAPACITY;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpyAsync(dst_device, h->c.results, sizeof(Result) * h->n_inst, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return RRTX_OK;
+}
+
 int rrtx_get_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap) {
   if (!h || !yaw || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
   if (!h->planned || !is_pose_tree(h->p.algo)) return RRTX_E_STATE;
@@ -792,7 +828,7 @@ int rrtx_get_path_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap
   if (!yaw) return RRTX_OK;
   if (cap_points < total) return RRTX_E_CAPACITY;
   int64_t k = 0;
-  yaw[k++] = h->p.goal[2];
+  yaw[k++] = I.goal[2];
   std::vector<double> bw;
   for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) {
     bw.resize(plen[nd]);
@@ -800,7 +836,7 @@ int rrtx_get_path_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap
                         sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
     for (int q = plen[nd] - 1; q >= 0; q--) yaw[k++] = bw[q];
   }
-  yaw[k] = h->p.start[2];
+  yaw[k] = I.start[2];
   return RRTX_OK;
 }
 

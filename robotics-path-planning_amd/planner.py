@@ -149,7 +149,7 @@ class _PlannerBase:
             h.set_rng_state(0, st)
             if self._trace:
                 h.enable_trace(0)
-            h.plan()
+            h.plan(strict=True)
             random.setstate(h.get_rng_state(0, st[2]))
             x, y, cost, parent = h.get_tree(0)
             self.node_list = NodeList(x, y, cost, parent, self.path_resolution)
@@ -310,7 +310,7 @@ class InformedRRTStar:
             h.set_rng_state(0, st)
             if self._trace:
                 h.enable_trace(0)
-            h.plan()
+            h.plan(strict=True)
             random.setstate(h.get_rng_state(0, st[2]))
             x, y, cost, parent = h.get_tree(0)
             nodes = []
@@ -396,7 +396,7 @@ class RRTStarDubins:
             h.set_rng_state(0, st)
             if self._trace:
                 h.enable_trace(0)
-            h.plan()
+            h.plan(strict=True)
             random.setstate(h.get_rng_state(0, st[2]))
             x, y, cost, parent = h.get_tree(0)
             yaw = h.get_yaw(0)
@@ -562,7 +562,7 @@ class BITStar:
             h.set_rng_state(0, st)
             if self._trace:
                 h.enable_trace(0)
-            h.plan()
+            h.plan(strict=True)
             random.setstate(h.get_rng_state(0, st[2]))
             self.tree_arrays = h.get_tree(0)
             path = h.get_path(0)
@@ -593,30 +593,61 @@ class BatchPlanner:
                  goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=False,
                  connect_circle_dist=50.0, search_until_max_iter=False, device=0, starts=None, goals=None,
                  curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.2):
-        """algo: "rrt" (rrt_01/02), "rrt_star" (rrt_04), and the pose planners (start / goal = [x, y, yaw]; curvature,
-        goal thresholds and, for Reeds-Shepp, step_size as in their constructors): "rrt_dubins" (rrt_03),
-        "rrt_star_dubins" (rrt_05), "rrt_star_reeds_shepp" (rrt_06).  `starts` / `goals` give per-instance x, y; for
-        the pose planners the start and goal yaw are `start[2]` / `goal[2]` for every instance."""
+        """algo: "rrt" (rrt_01/02), "rrt_star" (rrt_04), "informed" (rrt_07: expand_dis, goal_sample_rate, max_iter,
+        sobol_sampler as in its constructor :1029-1042), "bitstar" (rrt_08: max_iter = maxIter, rand_area = randArea
+        :140-168), and the pose planners (start / goal = [x, y, yaw]; curvature, goal thresholds and, for Reeds-Shepp,
+        step_size as in their constructors): "rrt_dubins" (rrt_03), "rrt_star_dubins" (rrt_05),
+        "rrt_star_reeds_shepp" (rrt_06).
+        `starts` / `goals`: per-instance [x, y] (pose planners: [x, y, yaw]; a missing yaw keeps `start[2]` /
+        `goal[2]`).  For "informed" and "bitstar" the rotation to the world frame and c_min (rrt_07:1054-1068,
+        rrt_08:189-202) are computed per instance on the host with numpy, as the reference does per planner object."""
         a = {"rrt": _abi.ALGO_RRT, "rrt_star": _abi.ALGO_RRT_STAR, "rrt_dubins": _abi.ALGO_RRT_DUBINS,
-             "rrt_star_dubins": _abi.ALGO_DUBINS, "rrt_star_reeds_shepp": _abi.ALGO_RS}[algo]
+             "rrt_star_dubins": _abi.ALGO_DUBINS, "rrt_star_reeds_shepp": _abi.ALGO_RS, "informed": _abi.ALGO_INFORMED,
+             "bitstar": _abi.ALGO_BITSTAR}[algo]
         self.seeds = list(seeds)
         self.pose = a in (_abi.ALGO_RRT_DUBINS, _abi.ALGO_DUBINS, _abi.ALGO_RS)
         self.algo = a
-        self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
-                             play_area=play_area, robot_radius=robot_radius,
-                             sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT,
-                             connect_circle_dist=connect_circle_dist, search_until_max_iter=search_until_max_iter,
-                             n_instances=len(self.seeds), device=device, curvature=curvature, goal_yaw_th=goal_yaw_th,
-                             goal_xy_th=goal_xy_th, step_size=step_size)
+        n = len(self.seeds)
+        rot_of = {_abi.ALGO_INFORMED: informed_rotation, _abi.ALGO_BITSTAR: bitstar_rotation}.get(a)
+        if a == _abi.ALGO_INFORMED:
+            c_min, c = informed_rotation(start, goal)
+            self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, 1.0, goal_sample_rate, max_iter,
+                                 sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT, n_instances=n,
+                                 device=device, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+        elif a == _abi.ALGO_BITSTAR:
+            c_min, c = bitstar_rotation(start, goal)
+            self.h = _abi.Handle(a, start, goal, rand_area, 2.0, 1.0, 0, max_iter, n_instances=n, device=device,
+                                 informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+        else:
+            self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
+                                 play_area=play_area, robot_radius=robot_radius,
+                                 sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT,
+                                 connect_circle_dist=connect_circle_dist, search_until_max_iter=search_until_max_iter,
+                                 n_instances=n, device=device, curvature=curvature, goal_yaw_th=goal_yaw_th,
+                                 goal_xy_th=goal_xy_th, step_size=step_size)
         self.h.set_obstacles(obstacle_list)
         self.h.seed_instances(self.seeds)
         if starts is not None or goals is not None:
-            for i in range(len(self.seeds)):
-                self.h.set_instance(i, None if starts is None else starts[i], None if goals is None else goals[i])
+            for i in range(n):
+                si = start if starts is None else starts[i]
+                gi = goal if goals is None else goals[i]
+                self.h.set_instance(i, None if starts is None else si, None if goals is None else gi)
+                if rot_of is not None:
+                    cm, ci = rot_of(si, gi)
+                    self.h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        self.partial = False
 
     def plan(self):
-        self.h.plan()
+        """Plans every instance; returns (path_cost, n_nodes, status) per instance.  An instance that stopped on a
+        capacity limit or where the reference would raise carries the bit in its status word (`failed()` lists
+        them); the other instances are complete.  Raises only for errors of the call as a whole."""
+        self.partial = self.h.plan() == _abi.RRTX_PARTIAL
         return self.h.get_results()
+
+    def failed(self):
+        """Indices of the instances without a result after plan(), with their status words."""
+        _, _, st = self.h.get_results()
+        return [(int(i), int(st[i])) for i in np.nonzero(st & _abi.ST_FAILED)[0]]
 
     def stats(self):
         return self.h.get_stats()

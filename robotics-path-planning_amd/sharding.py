@@ -15,21 +15,43 @@ def instance_owner(instance, per_rank):
     return instance // per_rank
 
 
-def gather_results(dist, path_cost, n_nodes, status, device=None):
+def gather_results(dist, path_cost, n_nodes, status, device=None, device_table=None):
     """all_gather of the result table; returns (path_cost, n_nodes, status) over all ranks, rank-major order.
-    With dist=None (single process) returns the inputs."""
+    With dist=None (single process) returns the inputs.  `device_table` = a planned `_abi.Handle`: the packed
+    16-byte records {f64 path_cost, i32 n_nodes, i32 status} are then copied device -> device into the tensor the
+    collective sends (rrtx_copy_results_device), with no round trip through host memory; otherwise (CPU / gloo tests)
+    the host arrays are packed into the same record layout."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return np.asarray(path_cost), np.asarray(n_nodes), np.asarray(status)
     import torch
-    rec = np.stack([np.asarray(path_cost, dtype=np.float64), np.asarray(n_nodes, dtype=np.float64),
-                    np.asarray(status, dtype=np.float64)], axis=1)
-    t = torch.from_numpy(rec)
-    if device is not None:
-        t = t.to(device)
+    n = len(path_cost)
+    if device_table is not None and device is not None:
+        t = torch.empty((n, 2), dtype=torch.int64, device=device)
+        device_table.copy_results_device(t.data_ptr(), t.numel() * 8)
+    else:
+        t = torch.from_numpy(pack_records(path_cost, n_nodes, status))
+        if device is not None:
+            t = t.to(device)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(out, t)
-    allr = torch.cat(out).cpu().numpy()
-    return allr[:, 0], allr[:, 1].astype(np.int64), allr[:, 2].astype(np.int64)
+    return unpack_records(torch.cat(out).cpu().numpy())
+
+
+RECORD = np.dtype([("path_cost", "<f8"), ("n_nodes", "<i4"), ("status", "<i4")])   # rppk::Result, 16 bytes
+
+
+def pack_records(path_cost, n_nodes, status):
+    """(n, 2) int64 view of the 16-byte result records."""
+    rec = np.zeros(len(path_cost), dtype=RECORD)
+    rec["path_cost"], rec["n_nodes"], rec["status"] = path_cost, n_nodes, status
+    return rec.view(np.int64).reshape(-1, 2)
+
+
+def unpack_records(a):
+    rec = np.ascontiguousarray(a, dtype=np.int64).reshape(-1).view(RECORD)
+    st = rec["status"].astype(np.int64)
+    pc = np.where((st & 2) != 0, rec["path_cost"], np.inf)   # rrtx_get_results: no path <=> +inf
+    return pc, rec["n_nodes"].astype(np.int64), st
 
 
 def reduce_max(dist, value, device=None):

@@ -46,7 +46,7 @@ def test_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(so)
     for name in sorted(declared):
         assert hasattr(lib, name), name
-    assert lib.rrtx_abi_version() == 2
+    assert lib.rrtx_abi_version() == int(re.search(r"#define RRTX_ABI_VERSION (\d+)", hdr).group(1))
     import rrt_amd
     assert set(rrt_amd._abi.EXPORTS) <= declared
 
@@ -65,6 +65,14 @@ def test_python_binding_mirrors_the_header():
     assert ids == {"RRTX_ALGO_RRT": A.ALGO_RRT, "RRTX_ALGO_RRT_STAR": A.ALGO_RRT_STAR, "RRTX_ALGO_INFORMED": A.ALGO_INFORMED,
                    "RRTX_ALGO_DUBINS": A.ALGO_DUBINS, "RRTX_ALGO_BITSTAR": A.ALGO_BITSTAR,
                    "RRTX_ALGO_RRT_DUBINS": A.ALGO_RRT_DUBINS, "RRTX_ALGO_RS": A.ALGO_RS}
+    # per-instance status bits and return codes: every one the header defines has a mirror of the same value
+    st = dict((k, int(v)) for k, v in re.findall(r"(RRTX_ST_[A-Z_]+) = (\d+)", hdr))
+    assert st == {"RRTX_ST_DONE": A.ST_DONE, "RRTX_ST_PATH": A.ST_PATH, "RRTX_ST_OVERFLOW": A.ST_OVERFLOW,
+                  "RRTX_ST_PATH_TRUNC": A.ST_PATH_TRUNC, "RRTX_ST_UNSUPPORTED": A.ST_UNSUPPORTED,
+                  "RRTX_ST_REF_RAISES": A.ST_REF_RAISES}
+    rcs = dict((k, int(v)) for k, v in re.findall(r"(RRTX_(?:OK|PARTIAL|E_[A-Z_]+)) = (-?\d+)", hdr))
+    assert rcs["RRTX_PARTIAL"] == A.RRTX_PARTIAL == 1 and rcs["RRTX_OK"] == 0
+    assert {v: k for k, v in rcs.items()} == {k: (v if v != "OK" else "RRTX_OK") for k, v in A.ERRORS.items()}
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "sz.c")
         open(src, "w").write('#include <stdio.h>\n#include <stddef.h>\n#include "rrtx.h"\nint main(void) { printf("%zu %zu %zu", '

@@ -751,3 +751,132 @@ def test_batch_planner_smooth_and_export(gpu, tmp_path):
         assert np.array_equal(sm[0], g["smoothed"])
     finally:
         bp.close()
+
+
+# ---------------------------------------------------------------- batch surface: per-instance problems (round-2)
+@pytest.mark.gpu
+def test_batch_planner_informed_per_instance_start_goal(gpu):
+    """BatchPlanner("informed"): every instance has its own start / goal, hence its own rotation C and c_min
+    (rrt_07:1054-1068, computed on the host with numpy as the reference does); instance i equals the oracle's run of that
+    problem, and instance 0 (the rrt_07 driver's problem, seed 42) equals the reference golden."""
+    import oracle
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt07_drv_mt_s42_it2000.npz")
+    kw = util.informed_kwargs_from_golden(g)
+    starts = [kw["start"], [1.0, 9.0], [11.0, 1.5], [0.5, 0.5]]
+    goals = [kw["goal"], [9.0, 1.0], [2.0, 12.0], [12.0, 11.0]]
+    seeds = [42, 5, 6, 7]
+    bp = rrt_amd.BatchPlanner("informed", seeds, kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], expand_dis=0.5,
+                              goal_sample_rate=10, max_iter=2000, sobol_sampler=False, starts=starts, goals=goals)
+    try:
+        pc, nn, st = bp.plan()
+        assert not bp.partial and bp.failed() == []
+        util.assert_tree_equal(bp.tree(0), (g["x"], g["y"], g["cost"], g["parent"]), "instance 0 = golden")
+        assert np.array_equal(bp.path(0), g["path"]) and pc[0] == float(g["path_len"])
+        for i in range(1, 4):
+            k2 = dict(kw)
+            k2.update(start=starts[i], goal=goals[i], max_iter=2000)
+            r = oracle.plan_informed(seed=seeds[i], **k2)
+            util.assert_tree_equal(bp.tree(i), (r["x"], r["y"], r["cost"], r["parent"]), "informed instance %d" % i)
+            assert (bp.path(i) is None) == (r["path"] is None)
+            if r["path"] is not None:
+                assert np.array_equal(bp.path(i), r["path"]) and pc[i] == r["c_best"]
+    finally:
+        bp.close()
+
+
+@pytest.mark.gpu
+def test_batch_planner_bitstar_per_instance_start_goal(gpu):
+    """BatchPlanner("bitstar") = BASELINE config C4's shape: per-instance start / goal; instance i equals the single
+    class `BITStar` seeded the same way, and the oracle."""
+    import random
+    import oracle
+    import rrt_amd
+    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+
+    def free_point(rng):
+        while True:
+            x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
+            if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
+                return [x, y]
+    n = 24
+    starts, goals, seeds = [], [], []
+    for i in range(n):
+        rng = random.Random(2000 + i)
+        starts.append(free_point(rng))
+        goals.append(free_point(rng))
+        seeds.append(1000 + i)
+    bp = rrt_amd.BatchPlanner("bitstar", seeds, starts[0], goals[0], obst, [-2.0, 15.0], max_iter=80, starts=starts,
+                              goals=goals)
+    try:
+        pc, nn, st = bp.plan()
+        for i in range(n):
+            r = oracle.plan_bitstar(starts[i], goals[i], obst, [-2, 15], 80, seed=seeds[i])
+            p = bp.path(i)
+            assert (p is None and len(r["path"]) == 0) or np.array_equal(p, r["path"]), i
+            assert np.array_equal(bp.tree(i)[2], r["g_scores"]), i
+        random.seed(seeds[3])
+        one = rrt_amd.BITStar(starts[3], goals[3], obst, [-2.0, 15.0], maxIter=80)
+        p1 = one.plan(animation=False)
+        p3 = bp.path(3)
+        assert (p3 is None and p1 == []) or np.array_equal(np.array(p1), p3)
+    finally:
+        bp.close()
+
+
+@pytest.mark.gpu
+def test_batch_planner_pose_per_instance_yaw(gpu):
+    """Per-instance start and goal POSES (x, y, yaw) for the pose planners (round-1 VERDICT missing 3): every instance
+    equals the oracle's run of that problem -- rrt_05 (Dubins), rrt_03 (RRT-Dubins) and rrt_06 (Reeds-Shepp)."""
+    import oracle
+    import rrt_amd
+    g5 = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it150.npz")
+    obst = [tuple(o) for o in g5["obstacles"]]
+    ra = list(g5["rand_area"])
+    starts = [list(g5["start"]), [0.0, 1.0, 0.7], [1.0, -1.0, -2.1], [12.0, 0.0, 3.0]]
+    goals = [list(g5["goal"]), [11.0, 9.0, 1.2], [10.0, 12.0, -0.4], [0.0, 12.0, 2.2]]
+    seeds = [42, 3, 4, 5]
+    bp = rrt_amd.BatchPlanner("rrt_star_dubins", seeds, starts[0], goals[0], obst, ra, goal_sample_rate=10, max_iter=300,
+                              search_until_max_iter=True, curvature=1.0, starts=starts, goals=goals)
+    try:
+        bp.plan()
+        for i in range(4):
+            r = oracle.plan_dubins(starts[i], goals[i], obst, ra, 300, seed=seeds[i])
+            util.assert_tree_equal(bp.tree(i), (r["x"], r["y"], r["cost"], r["parent"]), "rrt05 pose instance %d" % i)
+            assert np.array_equal(bp.yaw(i), r["yaw"])
+            assert (bp.path(i) is None) == (r["path"] is None)
+            if r["path"] is not None:
+                assert np.array_equal(bp.path(i), r["path"])
+    finally:
+        bp.close()
+    bp = rrt_amd.BatchPlanner("rrt_dubins", seeds, starts[0], goals[0], obst, ra, goal_sample_rate=10, max_iter=300,
+                              curvature=1.0, starts=starts, goals=goals)
+    try:
+        bp.plan()
+        for i in range(4):
+            r = oracle.plan_rrt_dubins(starts[i], goals[i], obst, ra, 300, seed=seeds[i])
+            util.assert_tree_equal(bp.tree(i), (r["x"], r["y"], r["cost"], r["parent"]), "rrt03 pose instance %d" % i)
+            assert np.array_equal(bp.yaw(i), r["yaw"])
+    finally:
+        bp.close()
+    g6 = util.load_golden(util.GOLDEN + "/rrt06_drv_s42_it200.npz")
+    obst6 = [tuple(o) for o in g6["obstacles"]]
+    starts6 = [list(g6["start"]), [0.0, 1.0, 0.7], [1.0, -1.0, -2.1]]
+    goals6 = [list(g6["goal"]), [11.0, 12.0, 1.2], [12.0, 2.0, -0.4]]
+    bp = rrt_amd.BatchPlanner("rrt_star_reeds_shepp", [42, 8, 9], starts6[0], goals6[0], obst6, list(g6["rand_area"]),
+                              expand_dis=3.0, goal_sample_rate=10, max_iter=200, robot_radius=0.6,
+                              search_until_max_iter=True, curvature=2.0, step_size=0.1, starts=starts6, goals=goals6)
+    try:
+        bp.plan()
+        assert np.array_equal(bp.path(0), g6["path"])
+        for i in range(3):
+            r = oracle.plan_rrt_rs(starts6[i], goals6[i], obst6, list(g6["rand_area"]), 200, seed=[42, 8, 9][i],
+                                   curvature=2.0, robot_radius=0.6, step_size=0.1)
+            util.assert_tree_equal(bp.tree(i), (r["x"], r["y"], r["cost"], r["parent"]), "rrt06 pose instance %d" % i)
+            assert np.array_equal(bp.yaw(i), r["yaw"])
+            p = bp.path(i)
+            assert (p is None) == (r["path"] is None)
+            if p is not None:
+                assert np.array_equal(p[:, :2], r["path"]) and np.array_equal(p[:, 2], r["path_yaw"])
+    finally:
+        bp.close()

@@ -83,7 +83,7 @@ def run_gpu_batch(kw, seeds, device=0, trace_instance=None):
         h.seed_instances(seeds)
         if trace_instance is not None:
             h.enable_trace(trace_instance)
-        h.plan()
+        h.plan(strict=True)
         out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], paths=[], rng=[])
         for i in range(len(seeds)):
             out["trees"].append(h.get_tree(i))
@@ -136,7 +136,7 @@ def run_gpu_informed(kw, seeds, device=0, trace_instance=None):
         h.seed_instances(seeds)
         if trace_instance is not None:
             h.enable_trace(trace_instance)
-        h.plan()
+        h.plan(strict=True)
         out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], paths=[], rng=[])
         for i in range(len(seeds)):
             out["trees"].append(h.get_tree(i))
@@ -167,7 +167,7 @@ def run_gpu_dubins(g, seeds, device=0, trace_instance=None, max_iter=None):
         h.seed_instances(seeds)
         if trace_instance is not None:
             h.enable_trace(trace_instance)
-        h.plan()
+        h.plan(strict=True)
         out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], yaws=[], polys=[], paths=[], rng=[])
         for i in range(len(seeds)):
             out["trees"].append(h.get_tree(i))
@@ -197,7 +197,7 @@ def run_gpu_rrt_dubins(g, seeds, device=0, trace_instance=None):
         h.seed_instances(seeds)
         if trace_instance is not None:
             h.enable_trace(trace_instance)
-        h.plan()
+        h.plan(strict=True)
         out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], yaws=[], polys=[], paths=[], rng=[], sobol=[])
         for i in range(len(seeds)):
             out["trees"].append(h.get_tree(i))
@@ -228,7 +228,7 @@ def run_gpu_rrt_rs(g, seeds, device=0, trace_instance=None):
         h.seed_instances(seeds)
         if trace_instance is not None:
             h.enable_trace(trace_instance)
-        h.plan()
+        h.plan(strict=True)
         out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], yaws=[], polys=[], paths=[], path_yaws=[], rng=[])
         for i in range(len(seeds)):
             out["trees"].append(h.get_tree(i))
@@ -260,7 +260,7 @@ def run_gpu_bitstar(obstacles, rand_area, max_iter, seeds, starts, goals, device
             h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
         if trace_instance is not None:
             h.enable_trace(trace_instance)
-        h.plan()
+        h.plan(strict=True)
         out = dict(stats=h.get_stats(), results=h.get_results(), trees=[], paths=[], rng=[])
         for i in range(len(seeds)):
             out["trees"].append(h.get_tree(i))
