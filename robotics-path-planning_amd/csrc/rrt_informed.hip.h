@@ -27,9 +27,13 @@ using rppk::FILTER_EPS;
 constexpr int TPB = 256;
 constexpr int NW = TPB / 64;
 constexpr int MAX_OBS = rppk::MAX_OBS;
-constexpr int NUI = 512;   // distinct near candidates held in LDS
+// NUI distinct near candidates held in LDS: 512 in the product shape (38 KB, 4 workgroups per CU); instances whose near
+// set outgrows it (the radius of rrt_07:1139 is not capped, so a tree confined to a pocket sees most of itself) are
+// planned again on the 2048-candidate shape (one workgroup per CU) -- rrtx_api.hip.
+constexpr int NUI_SMALL = 512, NUI_LARGE = 2048;
 
-struct ShI {
+template <int NUI>
+struct ShIT {
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   int32_t uidx[NUI], ufree[NUI];
@@ -67,9 +71,10 @@ __device__ __forceinline__ double seg_dist2(double vx, double vy, double wx, dou
 }
 
 // exact re-check + `.index` de-dup (rrt_07:1140-1142) into the candidate records (idx, d2, x, y, cost)
+template <int NUI>
 __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x, const double* __restrict__ y,
                                                    const double* __restrict__ cost, double qx, double qy,
-                                                   double thr_exact, const int32_t* hits, int kraw, ShI& sh) {
+                                                   double thr_exact, const int32_t* hits, int kraw, ShIT<NUI>& sh) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) {
     sh.nu = 0;
@@ -153,10 +158,11 @@ struct InformedArgs {
   double c_min2;
 };
 
-__global__ __launch_bounds__(TPB, 4) void rrt_informed_kernel(Ctx c, const InformedArgs* __restrict__ per_inst,
-                                                              double* cbest_io, int iters) {
-  __shared__ ShI sh;
-  const int inst = blockIdx.x;
+template <int NUI, int WPS>
+__global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const InformedArgs* __restrict__ per_inst,
+                                                                double* cbest_io, int iters) {
+  __shared__ ShIT<NUI> sh;
+  const int inst = c.inst_map ? c.inst_map[blockIdx.x] : blockIdx.x;
   const InformedArgs ia = per_inst[inst];   // rotation, centre and c_min**2 of THIS instance's start / goal pair
   const int tid = threadIdx.x;
   Inst* I = c.inst + inst;

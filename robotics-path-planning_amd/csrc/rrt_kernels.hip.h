@@ -97,6 +97,8 @@ struct Ctx {
   // the rrt_04 iteration kernel's streaming pass (scan2q); q_m = distance margin of that stage
   uint32_t* xq;
   double q_lo, q_inv, q_step, q_m;
+  // partial re-plan (overflow retry, rrtx_api.hip): block b works on instance inst_map[b]; nullptr = identity
+  const int32_t* inst_map;
   // elen[i] = hypot(node i - its parent), exactly the value calc_new_cost (rrt_04:1375-1377) would compute now;
   // kept by the v2 kernel so cost propagation needs no coordinates and no hypot
   double* elen;
@@ -863,7 +865,7 @@ __device__ __forceinline__ void draw_sample(const Ctx& c, SH& sh, rpp::Sobol& so
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
   __shared__ Sh sh;
-  const int inst = blockIdx.x;
+  const int inst = c.inst_map ? c.inst_map[blockIdx.x] : blockIdx.x;
   const int tid = threadIdx.x;
   Inst* I = c.inst + inst;
   if (I->status & 1) return;  // done
@@ -1248,7 +1250,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
 
 // initialise one instance's arrays: +inf padding, root node (rrt_04:1043)
 __global__ void rrt_init_kernel(Ctx c) {
-  const int inst = blockIdx.y;
+  const int inst = c.inst_map ? c.inst_map[blockIdx.y] : blockIdx.y;
   const int64_t off = (int64_t)inst * c.stride;
   const double inf = rpp::dinf();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < c.stride; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1262,8 +1264,9 @@ __global__ void rrt_init_kernel(Ctx c) {
   }
 }
 __global__ void rrt_root_kernel(Ctx c, int ninst) {
-  const int inst = blockIdx.x * blockDim.x + threadIdx.x;
-  if (inst >= ninst) return;
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= ninst) return;
+  const int inst = c.inst_map ? c.inst_map[slot] : slot;
   const int64_t off = (int64_t)inst * c.stride;
   Inst* I = c.inst + inst;
   c.x[off] = I->start[0];

@@ -59,6 +59,8 @@ struct rrtx_handle {
   std::string err;
   std::vector<void*> allocs;
   int chunk_iters = 1024;
+  int32_t* inst_map = nullptr;   // device: instance ids of a partial re-plan (overflow retry)
+  int64_t stats_retried = 0;
   int v2_chunk_iters = 16384;   // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
   std::vector<rppi::InformedArgs> iargs;   // informed RRT*: per-instance rotation C / c_min**2 (centre filled at plan time)
@@ -95,6 +97,58 @@ static int dalloc(rrtx_handle* h, T** p, size_t count) {
   h->allocs.push_back(q);
   *p = (T*)q;
   return 0;
+}
+
+
+// ---- RRT* (rrt_04, search_until_max_iter): iteration-kernel launches ------------------------------------------------
+// One pass of the latency-lean iteration kernel over `nblk` instances (c.inst_map selects them; nullptr = 0..nblk-1),
+// in chunks of h->v2_chunk_iters iterations, workgroup shape tpb in {64, 128, 256}.
+static int launch_rrt_star_v2(rrtx_handle* h, const Ctx& c, int nblk, int tpb, bool f32, double* kms, int64_t* launches) {
+  for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->v2_chunk_iters) {
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (tpb == 64) {
+      if (f32)
+        hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<true>, dim3(nblk), dim3(rppk2t::TPB), 0, h->stream, c, h->v2_chunk_iters);
+      else
+        hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<false>, dim3(nblk), dim3(rppk2t::TPB), 0, h->stream, c, h->v2_chunk_iters);
+    } else if (tpb == 128) {
+      if (f32)
+        hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<true>, dim3(nblk), dim3(rppk2s::TPB), 0, h->stream, c, h->v2_chunk_iters);
+      else
+        hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<false>, dim3(nblk), dim3(rppk2s::TPB), 0, h->stream, c, h->v2_chunk_iters);
+    } else {
+      if (f32)
+        hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<true>, dim3(nblk), dim3(rppk2::TPB), 0, h->stream, c, h->v2_chunk_iters);
+      else
+        hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<false>, dim3(nblk), dim3(rppk2::TPB), 0, h->stream, c, h->v2_chunk_iters);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *kms += ms;
+    (*launches)++;
+  }
+  return RRTX_OK;
+}
+
+// Near-candidate capacity of a shape (rrt_star_v2.hip.h RRT2_NU) and the obstacle tile it holds
+static int v2_shape_nu(int tpb) { return tpb == 64 ? rppk2t::NU : tpb == 128 ? rppk2s::NU : rppk2::NU; }
+static int v2_shape_maxobs(int tpb) { return tpb == 64 ? rppk2t::MAX_OBS : tpb == 128 ? rppk2s::MAX_OBS : rppk2::MAX_OBS; }
+
+// Expected size of the largest near set of a plan, for a tree that fills the sampling square evenly:
+// density * pi * r(n)^2 with r(n) of rrt_04:1329-1334 -> pi * min(ccd^2 ln n, n expand_dis^2) / area, largest at
+// n = max_iter + 1; a Poisson tail (6 sigma + 8) on top.  Trees are not even (obstacles, unexplored corners), so this
+// only steers the first choice of shape: an instance that still overflows is planned again on the next larger shape.
+static int estimate_near_capacity(const rrtx_params& p) {
+  const double n = (double)p.max_iter + 1.0;
+  const double side = fabs(p.rand_max - p.rand_min);
+  const double area = side * side > 1e-12 ? side * side : 1e-12;
+  double a = p.connect_circle_dist * p.connect_circle_dist * log(n > 2.0 ? n : 2.0), b = n * p.expand_dis * p.expand_dis;
+  const double lam = M_PI * (a < b ? a : b) / area;
+  const double cap = lam + 6.0 * sqrt(lam) + 8.0;
+  return cap > 1e6 ? 1000000 : (int)cap;
 }
 
 extern "C" {
@@ -495,11 +549,15 @@ int rrtx_plan(rrtx_handle* h) {
   // below then only performs the final goal search (rrt_04:1080-1084).  RRTX_KERNEL=v1 forces the general kernel.
   const char* kv = getenv("RRTX_KERNEL");
   const bool use_v2 = c.algo == RRTX_ALGO_RRT_STAR && c.until_max && !(kv && !strcmp(kv, "v1"));
+  int v2_tpb = 0;
+  bool v2_f32 = false;
   if (use_v2) {
-    // workgroup shape: fewer threads per instance once more instances want to be resident (8 / 16 workgroups per CU)
+    // workgroup shape: fewer threads per instance once more instances want to be resident (8 / 16 workgroups per CU),
+    // as long as the shape's obstacle tile and near-candidate capacity fit the problem
+    const int need_nu = estimate_near_capacity(h->p);
     int tpb = 256;
-    if (B > 1280 && c.m <= rppk2s::MAX_OBS) tpb = 128;
-    if (B > 2560 && c.m <= rppk2t::MAX_OBS) tpb = 64;
+    if (B > 1280 && c.m <= rppk2s::MAX_OBS && need_nu <= rppk2s::NU) tpb = 128;
+    if (B > 2560 && c.m <= rppk2t::MAX_OBS && need_nu <= rppk2t::NU) tpb = 64;
     if (const char* e = getenv("RRTX_TPB")) {
       const int v = atoi(e);
       tpb = (v == 64 && c.m <= rppk2t::MAX_OBS) ? 64 : (v == 128 && c.m <= rppk2s::MAX_OBS) ? 128 : 256;
@@ -508,32 +566,10 @@ int rrtx_plan(rrtx_handle* h) {
     // magnitude any node or sample can have (see scan2f)
     bool f32 = c.xf != nullptr;
     if (const char* e = getenv("RRTX_F32")) f32 = f32 && atoi(e) != 0;
-    for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->v2_chunk_iters) {
-      HIPCHK(h, hipEventRecord(h->ev0, h->stream));
-      if (tpb == 64) {
-        if (f32)
-          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->v2_chunk_iters);
-        else
-          hipLaunchKernelGGL(rppk2t::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2t::TPB), 0, h->stream, c, h->v2_chunk_iters);
-      } else if (tpb == 128) {
-        if (f32)
-          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->v2_chunk_iters);
-        else
-          hipLaunchKernelGGL(rppk2s::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2s::TPB), 0, h->stream, c, h->v2_chunk_iters);
-      } else {
-        if (f32)
-          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<true>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->v2_chunk_iters);
-        else
-          hipLaunchKernelGGL(rppk2::rrt_star_kernel_v2<false>, dim3(B), dim3(rppk2::TPB), 0, h->stream, c, h->v2_chunk_iters);
-      }
-      HIPCHK(h, hipGetLastError());
-      HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));
-      float ms = 0.f;
-      HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-      kms += ms;
-      launches++;
-    }
+    v2_tpb = tpb;
+    v2_f32 = f32;
+    int rc2 = launch_rrt_star_v2(h, c, B, tpb, f32, &kms, &launches);
+    if (rc2) return rc2;
   }
   if (c.algo == RRTX_ALGO_INFORMED) {
     std::vector<double> inf(B, INFINITY);
@@ -558,8 +594,8 @@ int rrtx_plan(rrtx_handle* h) {
   for (;;) {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (c.algo == RRTX_ALGO_INFORMED)
-      hipLaunchKernelGGL(rppi::rrt_informed_kernel, dim3(B), dim3(rppi::TPB), 0, h->stream, c, h->d_iargs, h->cbest,
-                         h->chunk_iters);
+      hipLaunchKernelGGL((rppi::rrt_informed_kernel<rppi::NUI_SMALL, 4>), dim3(B), dim3(rppi::TPB), 0, h->stream, c,
+                         h->d_iargs, h->cbest, h->chunk_iters);
     else if (is_dubins(c.algo))
       hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(B), dim3(rppd::TPB), 0, h->stream, c, h->da, h->chunk_iters);
     else if (c.algo == RRTX_ALGO_RS)
@@ -584,6 +620,109 @@ int rrtx_plan(rrtx_handle* h) {
     if (launches > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
       h->err = "planner kernel did not converge to DONE";
       return RRTX_E_STATE;
+    }
+  }
+  // RRT* iteration kernel: an instance whose near set outgrew the LDS candidate table of its workgroup shape
+  // (RRTX_ST_OVERFLOW) is planned again, from its staged start state, on the next larger shape (44 -> 128 -> 256
+  // candidates), and finally by the general kernel (512).  Same results as a first plan on that shape: every shape
+  // runs the same statements.
+  if (use_v2 && !getenv("RRTX_NO_RETRY")) {
+    int shape = v2_tpb;   // 0 = general kernel
+    for (;;) {
+      std::vector<int32_t> redo;
+      for (int i = 0; i < B; i++)
+        if (res[i].status & RRTX_ST_OVERFLOW) redo.push_back(i);
+      if (redo.empty() || shape == 0) break;
+      shape = shape == 64 ? 128 : shape == 128 ? 256 : 0;
+      if (shape && c.m > v2_shape_maxobs(shape)) continue;
+      const int nr = (int)redo.size();
+      if (!h->inst_map) {
+        int rc2;
+        if ((rc2 = dalloc(h, &h->inst_map, B))) return rc2;
+      }
+      HIPCHK(h, hipMemcpyAsync(h->inst_map, redo.data(), sizeof(int32_t) * nr, hipMemcpyHostToDevice, h->stream));
+      for (int k = 0; k < nr; k++)
+        HIPCHK(h, hipMemcpyAsync(c.inst + redo[k], &h->host_inst[redo[k]], sizeof(Inst), hipMemcpyHostToDevice, h->stream));
+      Ctx cr = c;
+      cr.inst_map = h->inst_map;
+      hipLaunchKernelGGL(rppk::rrt_init_kernel, dim3(64, nr), dim3(256), 0, h->stream, cr);
+      hipLaunchKernelGGL(rppk::rrt_root_kernel, dim3((nr + 63) / 64), dim3(64), 0, h->stream, cr, nr);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipStreamSynchronize(h->stream));   // `redo` is read by the copies above
+      if (shape) {
+        int rc2 = launch_rrt_star_v2(h, cr, nr, shape, v2_f32, &kms, &launches);
+        if (rc2) return rc2;
+      }
+      for (int64_t guard = 0;; guard++) {
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL(rppk::rrt_plan_kernel, dim3(nr), dim3(rppk::TPB), 0, h->stream, cr, h->chunk_iters);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        kms += ms;
+        launches++;
+        bool all = true;
+        for (int k = 0; k < nr; k++)
+          if (!(res[redo[k]].status & RRTX_ST_DONE)) all = false;
+        if (all) break;
+        if (guard > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
+          h->err = "planner kernel did not converge to DONE (overflow retry)";
+          return RRTX_E_STATE;
+        }
+      }
+      h->stats_retried += nr;
+    }
+  }
+  // Informed RRT*: the near radius of rrt_07:1139 is not capped, so a near set can outgrow the 512 LDS candidate slots
+  // of the product shape; those instances are planned again, from their staged start state, on the 2048-slot shape
+  // (one workgroup per CU).  Same statements, same results as a first plan on that shape.
+  if (c.algo == RRTX_ALGO_INFORMED && !getenv("RRTX_NO_RETRY")) {
+    std::vector<int32_t> redo;
+    for (int i = 0; i < B; i++)
+      if (res[i].status & RRTX_ST_OVERFLOW) redo.push_back(i);
+    if (!redo.empty()) {
+      const int nr = (int)redo.size();
+      if (!h->inst_map) {
+        int rc2;
+        if ((rc2 = dalloc(h, &h->inst_map, B))) return rc2;
+      }
+      HIPCHK(h, hipMemcpyAsync(h->inst_map, redo.data(), sizeof(int32_t) * nr, hipMemcpyHostToDevice, h->stream));
+      const double inf1 = INFINITY;
+      for (int k = 0; k < nr; k++) {
+        HIPCHK(h, hipMemcpyAsync(c.inst + redo[k], &h->host_inst[redo[k]], sizeof(Inst), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->cbest + redo[k], &inf1, sizeof(double), hipMemcpyHostToDevice, h->stream));
+      }
+      Ctx cr = c;
+      cr.inst_map = h->inst_map;
+      hipLaunchKernelGGL(rppk::rrt_init_kernel, dim3(64, nr), dim3(256), 0, h->stream, cr);
+      hipLaunchKernelGGL(rppk::rrt_root_kernel, dim3((nr + 63) / 64), dim3(64), 0, h->stream, cr, nr);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (int64_t guard = 0;; guard++) {
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        hipLaunchKernelGGL((rppi::rrt_informed_kernel<rppi::NUI_LARGE, 1>), dim3(nr), dim3(rppi::TPB), 0, h->stream, cr,
+                           h->d_iargs, h->cbest, h->chunk_iters);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        kms += ms;
+        launches++;
+        bool all = true;
+        for (int k = 0; k < nr; k++)
+          if (!(res[redo[k]].status & RRTX_ST_DONE)) all = false;
+        if (all) break;
+        if (guard > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
+          h->err = "planner kernel did not converge to DONE (overflow retry)";
+          return RRTX_E_STATE;
+        }
+      }
+      h->stats_retried += nr;
     }
   }
   // aggregate counters

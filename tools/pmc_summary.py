@@ -26,6 +26,8 @@ ap.add_argument("--max-iter", type=int, default=105000)
 ap.add_argument("--obstacles", type=int, default=50)
 ap.add_argument("--variant", default="q16_mirror")
 ap.add_argument("--alg-bytes", type=float, default=None)
+ap.add_argument("--workload", default="c2")
+ap.add_argument("--kernel-match", default="rrt_star_kernel_v2")
 a = ap.parse_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prof = os.path.join(root, "profiles")
@@ -55,16 +57,30 @@ for f in glob.glob(os.path.join(a.dir, "**", "*kernel_stats.csv"), recursive=Tru
     break
 
 def dominant(cn):
-    rows = [r for r in per_counter.get(cn, []) if "rrt_star_kernel_v2" in r[0]]
+    rows = [r for r in per_counter.get(cn, []) if a.kernel_match in r[0]]
     return max(rows, key=lambda r: r[3]) if rows else None
 
 fs, wsz = dominant("FETCH_SIZE"), dominant("WRITE_SIZE")
 if fs and wsz:
     rd, wr = fs[3] * 1024 * 2, wsz[3] * 1024
+    import hashlib
+    import subprocess
+    hh = hashlib.sha256()
+    cs = os.path.join(root, "robotics-path-planning_amd", "csrc")
+    for f in sorted(os.listdir(cs)):
+        if f.endswith((".h", ".inc", ".hip")):
+            hh.update(f.encode())
+            hh.update(open(os.path.join(cs, f), "rb").read())
+    try:
+        commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:  # noqa: BLE001  (the GPU box has no .git: the caller passes the hash through the environment)
+        commit = os.environ.get("RRTX_COMMIT", "unknown")
     tj = {"config": {"instances_per_gpu": a.instances, "max_iter": a.max_iter, "obstacles": a.obstacles,
                      "variant": a.variant},
+          "csrc_hash": hh.hexdigest()[:16], "commit": commit,
           "kernel": fs[0], "dispatches": fs[2], "FETCH_SIZE_KB": fs[3], "WRITE_SIZE_KB": wsz[3],
           "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_step": rd + wr,
+          "hbm_bytes_per_launch": (rd + wr) / max(fs[2], 1),
           "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python3 bench.py "
                     "--no-cpu-baseline --warmup 0 --steps 1` (tools/profile_headline.sh); read bytes = "
                     "FETCH_SIZE(KB)*1024*2 (gfx950 correction for 16-B/lane streaming loads, MI355X_MICROARCH.md HBM "
@@ -73,5 +89,7 @@ if fs and wsz:
         tj["algorithmic_bytes_per_step"] = a.alg_bytes
         tj["traffic_over_algorithmic"] = (rd + wr) / a.alg_bytes
     out = os.path.join(prof, "%s_traffic.json" % a.tag)
+    if a.tag.startswith("r2_"):
+        out = os.path.join(prof, "r2_%s_traffic.json" % a.workload)
     json.dump(tj, open(out, "w"), indent=1)
     print("wrote", out, json.dumps(tj))

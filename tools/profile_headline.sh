@@ -15,5 +15,5 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o write -- python3
 echo "WRITE_SIZE pass done"
 # keep only the summaries (the per-dispatch CSVs are small; drop big traces)
 find $OUT -name "*.db" -delete 2>/dev/null || true
-python3 $REPO/tools/pmc_summary.py $OUT $TAG
+python3 $REPO/tools/pmc_summary.py $OUT $TAG $SUMMARY_ARGS
 cp $REPO/profiles/${TAG}_* $REPO/gpurun_out/ 2>/dev/null || true
