@@ -116,15 +116,11 @@ def spawn_ranks(a):
 
 
 # ------------------------------------------------------------------------------------------------ workloads
-def csrc_hash():
-    """Identity of the device code the numbers belong to (PMC traffic files record it)."""
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "robotics-path-planning_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".h", ".inc", ".hip")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+def csrc_hash(workload):
+    """Identity of the device code the numbers belong to (tools/csrc_hash.py; the PMC files record it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import csrc_hash as ch
+    return ch.csrc_hash(workload)
 
 
 class Workload:
@@ -488,7 +484,7 @@ def main():
             tj = json.load(open(tfile))
             tc = tj["config"]
             if tc["instances_per_gpu"] == wl.B and tc["max_iter"] == wl.max_iter and tc["obstacles"] == wl.M:
-                if tj.get("csrc_hash") == csrc_hash():
+                if tj.get("csrc_hash") == csrc_hash(a.workload):
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
                     roof["traffic_per_step"] = tj["hbm_bytes_per_step"]
                     t_gbps = tj["hbm_bytes_per_step"] / 1e9 / (kms / 1e3 / sd)
@@ -499,17 +495,35 @@ def main():
                                             "this run's kernel time / peak" % (os.path.basename(tfile), tj.get("commit")))
                 else:
                     roof["traffic_note"] = "profiles/%s was measured on other device code (hash %s != %s): not used" % (
-                        os.path.basename(tfile), tj.get("csrc_hash"), csrc_hash())
+                        os.path.basename(tfile), tj.get("csrc_hash"), csrc_hash(a.workload))
         except (OSError, ValueError, KeyError):
             pass
+        # C3..C6: closed-form f64 geometry per candidate edge, small trees -- the kernels are bound by VALU issue and
+        # dependent-instruction latency, not by HBM.  Their roof is the VALU issue rate, measured by a rocprofv3 --pmc
+        # pass of this exact device code (tools/valu_pass.sh -> profiles/r2_<workload>_valu.json); the HBM figures stay
+        # next to it under "hbm".
         vfile = os.path.join(ROOT, "profiles", "r2_%s_valu.json" % a.workload)
-        try:
-            vj = json.load(open(vfile))
-            if vj.get("csrc_hash") == csrc_hash():
-                roof["valu"] = {k: vj[k] for k in ("valu_busy_frac", "valu_insts_per_launch", "f64_valu_note", "commit")
-                                if k in vj}
-        except (OSError, ValueError, KeyError):
-            pass
+        if a.workload != "c2":
+            try:
+                vj = json.load(open(vfile))
+            except (OSError, ValueError):
+                vj = None
+            if vj is not None and vj.get("csrc_hash") == csrc_hash(a.workload):
+                roof = {"bound": "valu", "achieved": 100.0 * vj["valu_busy_frac"], "peak": 100.0,
+                        "unit": "% of VALU issue slots", "frac": vj["valu_busy_frac"], "traffic": None,
+                        "kernel": kernel_name, "launches": state["launches"], "kernel_ms_per_step": kms / sd,
+                        "valu_insts_per_launch": vj.get("valu_insts_per_launch"),
+                        "active_lane_frac": vj.get("active_lane_frac"),
+                        "f64_flops_upper_TFLOPs": vj.get("f64_flops_upper_TFLOPs"), "f64_peak_TFLOPs": 78.6,
+                        "note": "VALU-issue roofline from rocprofv3 --pmc SQ_INSTS_VALU / _FMA_F64 / _ADD_F64 / _MUL_F64 / "
+                                "_TRANS_F64 of this device code (profiles/%s, commit %s): frac = (2 cycles x non-f64 + 4 cycles x "
+                                "f64 VALU instructions) / (kernel time x 2.4 GHz x 1024 SIMDs).  The kernel is latency bound "
+                                "(dependent f64 chains of the libm replicas on few lanes: active_lane_frac), HBM is idle"
+                                % (os.path.basename(vfile), vj.get("commit")),
+                        "hbm": roof}
+            else:
+                roof["note"] += ("; no VALU counters for this device code (profiles/%s missing or measured on other code): "
+                                 "only the HBM side is reported" % os.path.basename(vfile))
         line = {
             "metric": metric, "value": value, "unit": "edge expansions/s", "n_gpus": ngpu,
             "steps": state["steps_done"], "warmup": a.warmup,
@@ -529,7 +543,7 @@ def main():
                                            "ref_raises": int(((all_st & 32) != 0).sum())},
             "roofline": roof,
             "steps_requested": a.steps, "warmup_max_iter": a.warmup_max_iter or wl.max_iter,
-            "time_budget_s": a.max_seconds, "elapsed_s": elapsed(), "csrc_hash": csrc_hash(),
+            "time_budget_s": a.max_seconds, "elapsed_s": elapsed(), "csrc_hash": csrc_hash(a.workload),
             "value_note": "`value` counts the distinct collision-checked edges the device evaluates; "
                           "edge_expansions_reference_equivalent_per_s counts check_collision calls as the reference "
                           "makes them for the same trees (repeated near indices included, SURVEY R6)",
@@ -544,8 +558,6 @@ def main():
                                   "candidates that can change the result (DESIGN.md 5.5 / 5.7: same trees, several times "
                                   "fewer edges); the reference and the CPU baseline steer every near candidate -- compare "
                                   "plans_per_s / iterations_per_s with the CPU baseline, not the edge rates")
-            roof["note"] += ("; this kernel is f64-VALU / latency bound (closed-form trigonometry per candidate edge), its "
-                             "HBM fraction is low by construction -- see roofline.valu for the issue-side bound")
         if c4:
             line["unit"] = "edge expansions/s"
             roof["note"] += "; BIT* is an instance-parallel sequential search (one wave per instance, state in LDS)"

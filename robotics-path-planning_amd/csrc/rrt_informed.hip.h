@@ -36,6 +36,7 @@ template <int NUI>
 struct ShIT {
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
+  double orad[MAX_OBS];   // obstacle radius (sqrt of the threshold), rounded up: the cheap reject test of choose_parent
   int32_t uidx[NUI], ufree[NUI];
   // uval (d**2 of a candidate, duplicate collapse) and cval (per-thread scratch of the same phase) are dead before
   // choose_parent writes ud / uex: they share storage, which keeps the block under 40 KB (4 workgroups per CU)
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
     sh.ox[i] = c.ox[i];
     sh.oy[i] = c.oy[i];
     sh.othr[i] = c.othr[i];
+    sh.orad[i] = __builtin_sqrt(c.othr[i] > 0.0 ? c.othr[i] : 0.0) * (1.0 + 1e-12);
   }
   if (tid == 0) {
     sh.rng.pos = I->rng.pos;
@@ -346,9 +348,24 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         sh.ufree[e] = 1;
       }
       __syncthreads();
-      for (int p = tid; p < nu * c.m; p += TPB) {
-        const int e = p / c.m, k = p - e * c.m;
-        if (seg_dist2(sh.ux[e], sh.uy[e], sh.uex[e], sh.uey[e], sh.ox[k], sh.oy[k]) <= sh.othr[k]) sh.ufree[e] = 0;
+      // candidate x obstacle (check_collision :1271-1276 per candidate): a wave takes a candidate, its lanes the
+      // obstacles.  The exact segment distance (:1249-1261) is evaluated only for obstacles that can touch the segment:
+      // dist(p, segment) >= |p - midpoint| - half length, so |p - mid| > half length + radius (with 1e-9 of slack
+      // against the roundings of this test) leaves `distance**2 <= size**2` false whatever the exact form returns.
+      {
+        const int lane = tid & 63, w = tid >> 6;
+        for (int e = w; e < nu; e += NW) {
+          const double vx = sh.ux[e], vy = sh.uy[e], ex2 = sh.uex[e], ey2 = sh.uey[e];
+          const double mx = 0.5 * (vx + ex2), my = 0.5 * (vy + ey2), hl = 0.5 * sh.ud[e] * (1.0 + 1e-12);
+          bool hit = false;
+          for (int k = lane; k < c.m; k += 64) {
+            const double ddx = sh.ox[k] - mx, ddy = sh.oy[k] - my, t = hl + sh.orad[k];
+            if (ddx * ddx + ddy * ddy <= t * t * (1.0 + 1e-9)) {
+              if (seg_dist2(vx, vy, ex2, ey2, sh.ox[k], sh.oy[k]) <= sh.othr[k]) hit = true;
+            }
+          }
+          if (__ballot(hit) != 0ull && lane == 0) sh.ufree[e] = 0;
+        }
       }
       __syncthreads();
       s_eu += nu;

@@ -58,7 +58,7 @@ struct rrtx_handle {
   int64_t phase[16] = {0};
   std::string err;
   std::vector<void*> allocs;
-  int chunk_iters = 1024;
+  int chunk_iters = 8192;        // iterations per launch of the other planner kernels
   int32_t* inst_map = nullptr;   // device: instance ids of a partial re-plan (overflow retry)
   int64_t stats_retried = 0;
   int v2_chunk_iters = 16384;   // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
@@ -199,9 +199,9 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   memset(&h->c, 0, sizeof(h->c));
   // Iterations per kernel launch.  A launch ends when its slowest instance does, so short chunks leave the chip
   // part idle at the end of every launch: 1024-iteration chunks cost the C2 batch 9 % (103 launches) against one launch;
-  // 16384 keeps that under 2 % and still returns to the host every few seconds.
+  // 16384 (8192 for the other kernels) keeps that under 2 % and still returns to the host every few seconds.
   if (const char* e = getenv("RRTX_CHUNK_ITERS")) {
-    h->chunk_iters = atoi(e) > 0 ? atoi(e) : 1024;
+    h->chunk_iters = atoi(e) > 0 ? atoi(e) : 8192;
     h->v2_chunk_iters = h->chunk_iters;
   }
   *out = h;  // returned even on failure below so the caller can read last_error, then destroy

@@ -63,21 +63,17 @@ def dominant(cn):
 fs, wsz = dominant("FETCH_SIZE"), dominant("WRITE_SIZE")
 if fs and wsz:
     rd, wr = fs[3] * 1024 * 2, wsz[3] * 1024
-    import hashlib
     import subprocess
-    hh = hashlib.sha256()
-    cs = os.path.join(root, "robotics-path-planning_amd", "csrc")
-    for f in sorted(os.listdir(cs)):
-        if f.endswith((".h", ".inc", ".hip")):
-            hh.update(f.encode())
-            hh.update(open(os.path.join(cs, f), "rb").read())
+    import sys
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import csrc_hash as ch
     try:
         commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:  # noqa: BLE001  (the GPU box has no .git: the caller passes the hash through the environment)
         commit = os.environ.get("RRTX_COMMIT", "unknown")
     tj = {"config": {"instances_per_gpu": a.instances, "max_iter": a.max_iter, "obstacles": a.obstacles,
                      "variant": a.variant},
-          "csrc_hash": hh.hexdigest()[:16], "commit": commit,
+          "csrc_hash": ch.csrc_hash(a.workload), "commit": commit,
           "kernel": fs[0], "dispatches": fs[2], "FETCH_SIZE_KB": fs[3], "WRITE_SIZE_KB": wsz[3],
           "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_step": rd + wr,
           "hbm_bytes_per_launch": (rd + wr) / max(fs[2], 1),

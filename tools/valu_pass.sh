@@ -23,11 +23,8 @@ kern = max((k for k, c in s if c == "SQ_INSTS_VALU"), key=lambda k: s[(k, "SQ_IN
 c = {cn: s[(kern, cn)] for (k, cn) in s if k == kern}
 j = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
 kms = j["roofline"]["kernel_ms_per_step"]
-hh = hashlib.sha256()
-cs = os.path.join(repo, "robotics-path-planning_amd", "csrc")
-for f in sorted(os.listdir(cs)):
-    if f.endswith((".h", ".inc", ".hip")):
-        hh.update(f.encode()); hh.update(open(os.path.join(cs, f), "rb").read())
+sys.path.insert(0, os.path.join(repo, "tools"))
+import csrc_hash as ch
 f64 = c.get("SQ_INSTS_VALU_FMA_F64", 0) + c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0)
 other = c["SQ_INSTS_VALU"] - f64
 # issue model (MI355X_MICROARCH.md): a wave64 VALU instruction holds its SIMD-32 for 2 cycles, an f64 one for 4
@@ -42,7 +39,7 @@ res = {"workload": w, "kernel": kern, "dispatches": d[(kern, "SQ_INSTS_VALU")], 
        "f64_valu_note": "valu_busy_frac = (2 cycles x non-f64 VALU instructions + 4 cycles x f64 ones) / (kernel time x 2.4 GHz x "
                         "1024 SIMDs): the share of the chip's VALU issue slots this kernel fills; f64_flops_upper counts 64 lanes per "
                         "instruction (an upper bound: the kernels run many instructions on a few lanes, see active_lane_frac)",
-       "csrc_hash": hh.hexdigest()[:16], "commit": os.environ.get("RRTX_COMMIT", "unknown")}
+       "csrc_hash": ch.csrc_hash(w), "commit": os.environ.get("RRTX_COMMIT", "unknown")}
 json.dump(res, open(os.path.join(repo, "profiles", "r2_%s_valu.json" % w), "w"), indent=1)
 json.dump(res, open(os.path.join(repo, "gpurun_out", "r2_%s_valu.json" % w), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel", "valu_busy_frac", "f64_flops_upper_TFLOPs", "active_lane_frac", "kernel_ms_profiled_run")}))
