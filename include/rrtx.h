@@ -103,10 +103,10 @@ typedef struct rrtx_stats {
   int64_t rewires;           /* rrt_04:1368 successes */
   int64_t propagated;        /* nodes rewritten by propagate_cost_to_leaves (rrt_04:1379-1384) */
   int64_t scan_nodes;        /* nodes visited by nearest/near/goal scans */
-  int64_t algorithmic_bytes; /* bytes this implementation's algorithm must move: 8*n per pass over the f32 coordinate
-                                mirror (16*n per f64 pass: fallbacks, RRTX_F32=0, the other algorithms) + 16 per hit
-                                gathered + 48*k + 24*M + 28; the near pass of iteration i also serves the nearest query
-                                of i+1 */
+  int64_t algorithmic_bytes; /* bytes this implementation's algorithm must move: RRTX_ALGO_RRT_STAR 4*n per pass over the
+                                16-bit coordinate mirror (8*n per f32-mirror pass, 16*n per f64 pass: the fallbacks,
+                                RRTX_Q16=0 / RRTX_F32=0 and the other algorithms) + 16 per hit gathered + 48*k + 24*M +
+                                44; the near pass of iteration i also serves the nearest query of i+1 */
   int64_t exact_rescans;     /* nearest scans re-done with exact ** 2 (tie within filter margin) */
   int64_t total_nodes;
   int64_t launches;          /* kernel launches */
@@ -115,7 +115,8 @@ typedef struct rrtx_stats {
   int64_t algorithmic_bytes_two_scan; /* SURVEY.md 8d formula as written: 32*n + 48*k + 24*M + 28 per accepted iteration */
   int64_t near_unique_max;   /* largest number of distinct near candidates any iteration of any instance produced */
   int64_t f32_fallbacks;     /* nearest queries the f32-mirror pass could not decide (repeated with the f64 pass) */
-  int64_t q16_fallbacks;     /* nearest queries the 16-bit first stage could not decide (repeated with the f32 pass) */
+  int64_t q16_fallbacks;     /* nearest queries the 16-bit first stage could not decide on grid distances (decided by a
+                                second 16-bit pass that collects the candidates + their f64 coordinates) */
   int64_t reserved[4];
 } rrtx_stats;
 

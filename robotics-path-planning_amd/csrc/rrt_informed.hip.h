@@ -34,6 +34,7 @@ constexpr int NUI_SMALL = 512, NUI_LARGE = 2048;
 
 template <int NUI>
 struct ShIT {
+  static constexpr int kNU = NUI;
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   double orad[MAX_OBS];   // obstacle radius (sqrt of the threshold), rounded up: the cheap reject test of choose_parent
@@ -77,6 +78,13 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
                                                    const double* __restrict__ cost, double qx, double qy,
                                                    double thr_exact, const int32_t* hits, int kraw, ShIT<NUI>& sh) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // pow-free form first (rppk::fast_dedup): rrt_07's near sets hold hundreds of hits, two pow each in the exact form
+  if (rppk::fast_dedup(x, y, qx, qy, thr_exact, hits, kraw, sh, [&](int p, int idx, double hx, double hy) {
+        sh.ux[p] = hx;
+        sh.uy[p] = hy;
+        sh.ucost[p] = cost[idx];
+      }))
+    return;
   if (tid == 0) {
     sh.nu = 0;
     sh.nvalid = 0;

@@ -269,3 +269,22 @@ def test_reeds_shepp_oracle_matches_reference_kat():
         assert np.array_equal(px, g["poly_x"][off:off + n]) and np.array_equal(py, g["poly_y"][off:off + n]), k
         assert np.array_equal(pyaw, g["poly_yaw"][off:off + n]), k
         off += n
+
+
+def test_oracle_diagnostic_counters_are_exported():
+    """The counters the device-side shortcuts are argued with: moved / revisited nodes of rrt_04's
+    rewire and late-qualifying rewire candidates of rrt_05 -- present, and moving in the expected direction."""
+    import ctypes as C
+    import oracle
+    L = oracle.lib()
+    m0, r0, m1, r1 = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+    L.orc_moved_counters(C.byref(m0), C.byref(r0))
+    kw = dict(util.C2)
+    kw.update(start=[0, 0], goal=[6, 8], rand_area=[-2, 12], obstacles=[(3, 3, 1)], expand_dis=3.0, path_resolution=0.05,
+              goal_sample_rate=60, max_iter=400)
+    util.run_oracle(kw, 5, exact_pow=True)
+    L.orc_moved_counters(C.byref(m1), C.byref(r1))
+    assert m1.value - m0.value == 17 and r1.value == r0.value     # tools/find_moved_node.py: 17 moved nodes, no second visit
+    q, w = C.c_long(), C.c_long()
+    L.orc_late_counters(C.byref(q), C.byref(w))
+    assert q.value >= w.value >= 0

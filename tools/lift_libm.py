@@ -27,7 +27,8 @@ Branches that leave the restated domain (huge-argument reduction `__branred`,
 overflow/underflow error exits of pow) return NaN and raise the `ood` flag.
 
 Output: one header with `static inline double rpp_glibc_{sin,cos,atan2,pow,acos,asin}`.
-Verified against the live libm by tests/test_glibc_math.py.
+Verified against the live libm by tests/test_core_host.py::test_glibc_replicas_against_live_libm
+(tests/native/glibc_replica_check.c) and on the device by tests/test_gpu_parity.py::test_device_arithmetic_replicas.
 
 Usage: python tools/lift_libm.py [--libm PATH] [--out HEADER]
 """

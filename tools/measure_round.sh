@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-end measurement set (GPU box, through gpurun; RRTX_COMMIT=<short hash> in the environment):
+#   1. rocprofv3 passes of the headline bench: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)
+#      -> profiles/r2_c2_kernel_stats.csv, r2_c2_pmc_*.csv, r2_c2_traffic.json (device-code hash + commit inside)
+#   2. the driver's exact bench command under its 600 s limit -> r2_bench_c2_driver_cmd.json (reads the traffic file of 1.)
+#   3. per-phase split of the C2 iteration (diagnostic build) -> r2_c2_phase_4096x105k.txt
+#   4. C3..C6: bench line + VALU PMC pass -> r2_bench_<w>.json, r2_<w>_valu.json
+# Everything is written under gpurun_out/r2/ (merged back by gpurun); copy it into profiles/ and commit.
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+O=$REPO/gpurun_out/r2
+mkdir -p $O
+cd $REPO
+SUMMARY_ARGS="--workload c2" bash tools/profile_headline.sh r2_c2 > $O/profile_headline.log 2>&1
+cp profiles/r2_c2_* $O/ 2>/dev/null
+tail -2 $O/profile_headline.log
+timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r2_bench_c2_driver_cmd.json 2> $O/bench_driver.err
+echo "driver bench rc=$?"
+RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile.py 4096 105000 > $O/r2_c2_phase_4096x105k.txt 2>&1
+echo "phase rc=$?"
+for w in c3 c4 c5 c6; do
+  bash tools/valu_pass.sh $w > $O/valu_$w.log 2>&1
+  cp gpurun_out/r2_${w}_valu.json $O/ 2>/dev/null
+  cp gpurun_out/r2_${w}_valu.json profiles/ 2>/dev/null
+  timeout -k 10 150 python3 bench.py --workload $w --warmup 1 --steps 5 > $O/r2_bench_$w.json 2> $O/bench_$w.err
+  echo "bench $w rc=$?"
+done
+timeout -k 10 120 tools/ubench/lat_ubench > $O/r2_lat_ubench.txt 2>&1
+python3 - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r2/r2_bench_*.json")):
+    try:
+        j = json.loads(open(f).read().strip().splitlines()[-1]); r = j["roofline"]
+        print(f.split("/")[-1], "steps", j["steps"], "ms/step %.1f" % j["ms_per_step"], "value %.4g" % j["value"],
+              "bound", r["bound"], "frac", r["frac"], "traffic_frac", r.get("traffic_frac"), "elapsed %.0f" % j["elapsed_s"])
+    except Exception as e:
+        print(f, "ERR", e)
+PY

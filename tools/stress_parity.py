@@ -19,9 +19,17 @@ G07D = util.load_golden(sorted(util.golden_files("rrt07_drv"))[0])
 
 
 def o05(a):
+    import ctypes as C
     import oracle
     sd, it = a
     r = oracle.plan_dubins(G05["start"], G05["goal"], G05["obstacles"], G05["rand_area"], it, seed=sd)
+    # rewire candidates that fail improved_cost before the loop and pass at their visit (the device's filtered stage
+    # steers them late, rrt_dubins.hip.h): cumulative per worker process, printed by the parent for the curious
+    q, w = C.c_long(), C.c_long()
+    oracle.lib().orc_late_counters(C.byref(q), C.byref(w))
+    if q.value:
+        print("  [oracle] rrt_05 seed %d: late-qualifying rewire candidates so far %d (rewired %d)" % (sd, q.value, w.value),
+              flush=True)
     return r["x"], r["y"], r["cost"], r["parent"]
 
 
