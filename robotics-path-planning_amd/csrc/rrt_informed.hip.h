@@ -34,7 +34,6 @@ constexpr int NUI_SMALL = 512, NUI_LARGE = 2048;
 
 template <int NUI>
 struct ShIT {
-  static constexpr int kNU = NUI;
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   double orad[MAX_OBS];   // obstacle radius (sqrt of the threshold), rounded up: the cheap reject test of choose_parent
@@ -78,13 +77,6 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
                                                    const double* __restrict__ cost, double qx, double qy,
                                                    double thr_exact, const int32_t* hits, int kraw, ShIT<NUI>& sh) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  // pow-free form first (rppk::fast_dedup): rrt_07's near sets hold hundreds of hits, two pow each in the exact form
-  if (rppk::fast_dedup(x, y, qx, qy, thr_exact, hits, kraw, sh, [&](int p, int idx, double hx, double hy) {
-        sh.ux[p] = hx;
-        sh.uy[p] = hy;
-        sh.ucost[p] = cost[idx];
-      }))
-    return;
   if (tid == 0) {
     sh.nu = 0;
     sh.nvalid = 0;
@@ -103,27 +95,20 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
       valid = v <= thr_exact;
     }
     const int nu = sh.nu;
-    bool cand = valid;
-    if (cand) {
-      for (int u = 0; u < nu; u++) {
-        if (sh.uval[u] == v) {
-          cand = false;
-          break;
-        }
-      }
-    }
-    sh.cval[tid] = v;
+    // "an equal value is held by an earlier entry" (rppk::exact_dedup): uniform trip counts, broadcast LDS reads, no
+    // early exit -- rrt_07's near sets hold hundreds of hits and these loops were the longest part of the phase
+    bool dupe = false;
+#pragma unroll 4
+    for (int u = 0; u < nu; u++) dupe |= (sh.uval[u] == v);
+    const bool cand = valid && !dupe;
+    sh.cval[tid] = cand ? v : rpp::b2d(0x7ff8000000000000ULL);   // NaN: never equal
     sh.cflag[tid] = cand ? 1 : 0;
     __syncthreads();
-    bool first = cand;
-    if (cand) {
-      for (int t = 0; t < tid; t++) {
-        if (sh.cflag[t] && sh.cval[t] == v) {
-          first = false;
-          break;
-        }
-      }
-    }
+    const int nchunk = (kraw - base) < TPB ? (kraw - base) : TPB;
+    bool earlier = false;
+#pragma unroll 4
+    for (int t = 0; t < nchunk; t++) earlier |= (t < tid) & (sh.cval[t] == v);
+    const bool first = cand && !earlier;
     const uint64_t mf = __ballot(first), mv = __ballot(valid);
     if (lane == 0) {
       sh.red_idx[w] = __popcll(mf);

@@ -495,27 +495,21 @@ __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const 
       valid = v <= thr_exact;
     }
     const int nu = sh.nu;
-    bool cand = valid;
-    if (cand) {
-      for (int u = 0; u < nu; u++) {
-        if (sh.uval[u] == v) {
-          cand = false;
-          break;
-        }
-      }
-    }
-    sh.cval[tid] = v;
+    // "an equal value is held by an earlier entry": both searches run the same trip count on every lane with
+    // broadcast LDS reads and no early exit -- throughput-bound instead of a dependent read-compare-branch per step
+    // (near sets of hundreds of nodes made these loops the longest part of the candidate phase)
+    bool dupe = false;
+#pragma unroll 4
+    for (int u = 0; u < nu; u++) dupe |= (sh.uval[u] == v);
+    const bool cand = valid && !dupe;
+    sh.cval[tid] = cand ? v : rpp::b2d(0x7ff8000000000000ULL);   // NaN: never equal
     sh.cflag[tid] = cand ? 1 : 0;
     __syncthreads();
-    bool first = cand;
-    if (cand) {
-      for (int t = 0; t < tid; t++) {
-        if (sh.cflag[t] && sh.cval[t] == v) {
-          first = false;
-          break;
-        }
-      }
-    }
+    const int nchunk = (kraw - base) < TPB ? (kraw - base) : TPB;
+    bool earlier = false;
+#pragma unroll 4
+    for (int t = 0; t < nchunk; t++) earlier |= (t < tid) & (sh.cval[t] == v);
+    const bool first = cand && !earlier;
     uint64_t mf = __ballot(first), mv = __ballot(valid);
     // per-wave counts through red_idx (free between reductions)
     if (lane == 0) {
@@ -548,109 +542,6 @@ __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const 
     }
     __syncthreads();
   }
-}
-
-// Pow-free form of exact_dedup (mode 0), same outputs except that sh.uval holds vf = dx*dx + dy*dy (correctly rounded
-// squares) instead of the reference's v = dx**2 + dy**2.  v is within 2^-51 relative of vf, so
-//   * vf outside [r2 (1 - eps), r2 (1 + eps)], eps = 2^-47, decides `v <= r**2` without pow;
-//   * two hits can hold the SAME v (the `.index` collapse) only if their vf differ by less than eps vf; nodes with
-//     identical coordinates certainly do.
-// A hit in the band, or a close pair of DIFFERENT nodes (coordinates compared, fetched only for such pairs), makes it
-// return false: the caller then runs exact_dedup over the whole list (the boundary case, not the rule).
-// store(p, idx, hx, hy): extra per-candidate outputs of the caller.  Uses sh.flag as a block-wide OR.
-template <class SH, class STORE>
-__device__ __forceinline__ bool fast_dedup(const double* __restrict__ x, const double* __restrict__ y, double qx,
-                                           double qy, double thr_exact, const int32_t* hits, int kraw, SH& sh,
-                                           STORE store) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) {
-    sh.nu = 0;
-    sh.nvalid = 0;
-    sh.flag = 0;
-  }
-  __syncthreads();
-  const double lo = thr_exact * (1.0 - FILTER_EPS), hi = thr_exact * (1.0 + FILTER_EPS);
-  for (int base = 0; base < kraw; base += TPB) {
-    const int h = base + tid;
-    int idx = -1;
-    double vf = 0.0, hx = 0.0, hy = 0.0;
-    int st = 0;   // 0 outside, 1 inside, 2 in the band
-    if (h < kraw) {
-      idx = hit_at(hits, sh, h);
-      hx = x[idx];
-      hy = y[idx];
-      vf = rpp::fast_d2(hx - qx, hy - qy);
-      st = vf <= lo ? 1 : (vf > hi ? 0 : 2);
-    }
-    const int nu = sh.nu;
-    bool need = st == 2, cand = st == 1;
-    if (cand) {
-      for (int u = 0; u < nu; u++) {   // candidates of earlier chunks
-        const double vt = sh.uval[u];
-        const double dv = vt > vf ? vt - vf : vf - vt;
-        if (dv <= FILTER_EPS * vf) {
-          const int ui = sh.uidx[u];
-          if (vt == vf && x[ui] == hx && y[ui] == hy) {
-            cand = false;   // same coordinates as an earlier candidate: same value, that one holds it
-            break;
-          }
-          need = true;      // different nodes, values possibly equal: the exact form decides
-        }
-      }
-    }
-    sh.cval[tid] = vf;
-    sh.cflag[tid] = cand ? idx + 1 : 0;
-    __syncthreads();
-    bool first = cand;
-    if (cand) {
-      for (int t = 0; t < tid; t++) {   // earlier hits of this chunk
-        const int ft = sh.cflag[t];
-        if (!ft) continue;
-        const double vt = sh.cval[t];
-        const double dv = vt > vf ? vt - vf : vf - vt;
-        if (dv <= FILTER_EPS * vf) {
-          if (vt == vf && x[ft - 1] == hx && y[ft - 1] == hy) {
-            first = false;
-            break;
-          }
-          need = true;
-        }
-      }
-    }
-    if (need) sh.flag = 1;
-    const uint64_t mf = __ballot(first), mv = __ballot(st == 1);
-    if (lane == 0) {
-      sh.red_idx[w] = __popcll(mf);
-      atomicAdd(&sh.nvalid, __popcll(mv));
-    }
-    __syncthreads();
-    if (sh.flag) return false;   // block-uniform
-    int off = nu, tot = nu;
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-      if (k < w) off += sh.red_idx[k];
-      tot += sh.red_idx[k];
-    }
-    if (first) {
-      const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-      const int p = off + __popcll(mf & lt_mask);
-      if (p < SH::kNU) {
-        sh.uval[p] = vf;
-        sh.uidx[p] = idx;
-        store(p, idx, hx, hy);
-      }
-    }
-    __syncthreads();
-    if (tid == 0) {
-      if (tot > SH::kNU) {
-        sh.overflow = 1;
-        tot = SH::kNU;
-      }
-      sh.nu = tot;
-    }
-    __syncthreads();
-  }
-  return true;
 }
 
 // ---------------------------------------------------------------------------
