@@ -172,6 +172,10 @@ int rrtx_get_stats(rrtx_handle* h, rrtx_stats* st);
 int rrtx_enable_trace(rrtx_handle* h, int32_t instance);
 int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* nearest, int32_t* n_near,
                    int32_t cap, int32_t* n_out);
+/* RRTX_ALGO_RRT / RRTX_ALGO_RRT_STAR, same rows: what the iteration appended -- 0 nothing, 1 the extension edge itself
+ * (rrt_01:85-96; rrt_04:1066-1067, choose_parent returned None), 2 a node under a chosen parent (rrt_04:1062-1065).  With
+ * rnd / nearest this lets the host rebuild Node.path_x / path_y exactly as the reference holds them (draw data). */
+int rrtx_get_trace_kind(rrtx_handle* h, int32_t* kind, int32_t cap, int32_t* n_out);
 /* diagnostic builds only (-DRRTX_PHASE_TIMERS): shader-clock cycles per kernel phase summed over instances
  * (0 sample, 1 nearest scan, 2 steer, 3 extension collision, 4 near scan, 5 exact re-check + de-dup,
  *  6 choose_parent edges, 7 choose_parent costs, 8 rewire edges, 9 rewire resolve + propagate + append,

@@ -24,7 +24,7 @@ ERRORS = {1: "RRTX_PARTIAL", 0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVIC
 EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obstacles", "rrtx_set_rng_state",
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_copy_results_device", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
-           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
+           "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_trace_kind", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
            "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw"]
 
 
@@ -90,6 +90,7 @@ def load():
     L.rrtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.rrtx_enable_trace.argtypes = [vp, i32]
     L.rrtx_get_trace.argtypes = [vp, vp, vp, vp, vp, i32, C.POINTER(i32)]
+    L.rrtx_get_trace_kind.argtypes = [vp, vp, i32, C.POINTER(i32)]
     L.rrtx_get_phase_cycles.argtypes = [vp, vp]
     L.rrtx_last_error.argtypes = [vp]
     L.rrtx_last_error.restype = C.c_char_p
@@ -318,6 +319,14 @@ class Handle:
                                         C.byref(n)), "rrtx_get_trace")
         k = n.value
         return rx[:k], ry[:k], ne[:k], nn[:k]
+
+    def get_trace_kind(self):
+        """Per iteration (rrt_01 / rrt_02 / rrt_04): 0 nothing appended, 1 the extension edge itself, 2 under a chosen parent."""
+        n = C.c_int32()
+        cap = max(self.max_iter + 1, 1 << 16)
+        kind = np.zeros(cap, dtype=np.int32)
+        self._chk(self.L.rrtx_get_trace_kind(self._h, kind.ctypes.data, cap, C.byref(n)), "rrtx_get_trace_kind")
+        return kind[:n.value]
 
 
 def smooth_paths(paths, max_iter, obstacles, rng_states, device=0):

@@ -90,6 +90,7 @@ struct Ctx {
   int32_t trace_inst;
   double *tr_rx, *tr_ry;
   int32_t *tr_near, *tr_nn;
+  int32_t* tr_kind;   // per iteration: 0 no node appended, 1 the extension itself (rrt_01:85-96, rrt_04:1066-1067), 2 under a chosen parent (:1062-1065)
   // f32 mirror of x[], y[] (prefilter of the streaming pass, rrt_star_v2_body.inc) and its distance margin
   float *xf, *yf;
   double f32_m;
@@ -964,9 +965,11 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
     __syncthreads();
     const int accepted = inplay && !sh.ecoll[0];
     int nnear = -1;
+    int node_kind = 0;
     PH(3);
 
     if (accepted && c.algo == 0) {
+      node_kind = 1;
       // ---- rrt_01:85-96
       if (tid == 0) {
         x[n] = nx;
@@ -1149,7 +1152,9 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
         s_pr += sh.sel;
         if (sh.nvalid) have_nearest = 0;  // a rewired node changed coordinates: the prefetched argmin is stale
         n++;
+        node_kind = 2;
       } else {
+        node_kind = 1;
         // choose_parent returned None: append the extension as it is (:1066-1067)
         if (tid == 0) {
           x[n] = nx;
@@ -1182,6 +1187,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
       c.tr_ry[it] = ry;
       c.tr_near[it] = ni;
       c.tr_nn[it] = nnear;
+      c.tr_kind[it] = node_kind;
     }
 
     // ---------------- early exit :1072-1076

@@ -456,6 +456,8 @@ int rrtx_enable_trace(rrtx_handle* h, int32_t instance) {
     if ((rc = dalloc(h, &h->c.tr_ry, n))) return rc;
     if ((rc = dalloc(h, &h->c.tr_near, n))) return rc;
     if ((rc = dalloc(h, &h->c.tr_nn, n))) return rc;
+    if ((rc = dalloc(h, &h->c.tr_kind, n))) return rc;
+    HIPCHK(h, hipMemset(h->c.tr_kind, 0, sizeof(int32_t) * n));
   }
   h->c.trace_inst = instance;
   return RRTX_OK;
@@ -1061,6 +1063,19 @@ int rrtx_get_trace(rrtx_handle* h, double* rnd_x, double* rnd_y, int32_t* neares
   if (rnd_y) HIPCHK(h, hipMemcpy(rnd_y, h->c.tr_ry, sizeof(double) * n, hipMemcpyDeviceToHost));
   if (nearest) HIPCHK(h, hipMemcpy(nearest, h->c.tr_near, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
   if (n_near) HIPCHK(h, hipMemcpy(n_near, h->c.tr_nn, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return RRTX_OK;
+}
+
+int rrtx_get_trace_kind(rrtx_handle* h, int32_t* kind, int32_t cap, int32_t* n_out) {
+  if (!h || !n_out) return RRTX_E_INVALID;
+  if (!h->planned || h->trace_inst < 0 || !h->c.tr_kind) return RRTX_E_STATE;
+  if (h->p.algo != RRTX_ALGO_RRT && h->p.algo != RRTX_ALGO_RRT_STAR) return RRTX_E_STATE;
+  HIPCHK(h, hipSetDevice(h->device));
+  Inst I;
+  HIPCHK(h, hipMemcpy(&I, h->c.inst + h->trace_inst, sizeof(I), hipMemcpyDeviceToHost));
+  *n_out = I.it;
+  if (cap < I.it) return RRTX_E_CAPACITY;
+  if (kind) HIPCHK(h, hipMemcpy(kind, h->c.tr_kind, sizeof(int32_t) * I.it, hipMemcpyDeviceToHost));
   return RRTX_OK;
 }
 

@@ -65,18 +65,58 @@ def _steer_polyline(fx, fy, tx, ty, extend, res):
     return px, py
 
 
+def _creation_records(trace, kind, n_nodes):
+    """(nearest, sample x, sample y, kind) per NODE from the per-ITERATION trace: iterations that appended a node
+    (kind 1 / 2) did so in order, node 0 is the start."""
+    rx, ry, nearest, _ = trace
+    k = min(len(kind), len(rx))
+    it = np.nonzero(kind[:k] > 0)[0]
+    if len(it) != n_nodes - 1:      # early exit of a launch chunk etc.: no record rather than a wrong one
+        return None
+    c_near = np.full(n_nodes, -1, dtype=np.int64)
+    c_rx = np.zeros(n_nodes)
+    c_ry = np.zeros(n_nodes)
+    c_kind = np.zeros(n_nodes, dtype=np.int64)
+    c_near[1:], c_rx[1:], c_ry[1:], c_kind[1:] = nearest[it], rx[it], ry[it], kind[it]
+    return c_near, c_rx, c_ry, c_kind
+
+
 class NodeList:
     """Lazy `node_list`: SoA arrays from the device, Node objects made on access.
 
     Parents are object references as in rrt_01/rrt_04 (the same Node object is
-    returned for the same index, so identity comparisons behave)."""
+    returned for the same index, so identity comparisons behave).
 
-    def __init__(self, x, y, cost, parent, res):
+    `path_x` / `path_y` (what draw_graph plots, rrt_04:1165-1167) are rebuilt on the host with CPython's own math, as
+    the reference built them.  A node holds the polyline of the steer() call that produced its current entry in
+    node_list:
+      * re-pointed by a later rewire (its parent index is larger than its own: `node_list[i] = edge_node`, :1372):
+        steer(parent -> node, inf) (:1359);
+      * appended as the extension itself (rrt_01:85-96; rrt_04:1066-1067 when choose_parent returned None):
+        steer(nearest -> sample, expand_dis) (:1051);
+      * appended under a chosen parent: steer(parent -> extension end, inf) (:1279).
+    `creation` = (nearest index, sample x, sample y, kind) per node, from the device's per-iteration trace
+    (rrtx_get_trace / rrtx_get_trace_kind); without it every node falls back to steer(parent -> node, inf)."""
+
+    def __init__(self, x, y, cost, parent, res, expand_dis=None, creation=None):
         self._x, self._y, self._cost, self._parent, self._res = x, y, cost, parent, res
+        self._expand_dis, self._creation = expand_dis, creation
         self._cache = {}
 
     def __len__(self):
         return len(self._x)
+
+    def _polyline(self, j, pj):
+        cr = self._creation
+        if cr is not None and pj < j and cr[3][j] > 0:
+            ne = int(cr[0][j])
+            ex, ey = _steer_polyline(float(self._x[ne]), float(self._y[ne]), float(cr[1][j]), float(cr[2][j]),
+                                     self._expand_dis, self._res)
+            if cr[3][j] == 1:
+                return ex, ey
+            return _steer_polyline(float(self._x[pj]), float(self._y[pj]), ex[-1], ey[-1], float("inf"), self._res)
+        return _steer_polyline(float(self._x[pj]), float(self._y[pj]), float(self._x[j]), float(self._y[j]),
+                               float("inf"), self._res)
 
     def _make(self, i):
         nd = self._cache.get(i)
@@ -93,9 +133,8 @@ class NodeList:
             n.cost = float(self._cost[j])
             pj = int(self._parent[j])
             if pj >= 0:
-                par = self._cache[pj]
-                n.parent = par
-                n.path_x, n.path_y = _steer_polyline(par.x, par.y, n.x, n.y, float("inf"), self._res)
+                n.parent = self._cache[pj]
+                n.path_x, n.path_y = self._polyline(j, pj)
             self._cache[j] = n
         return self._cache[i]
 
@@ -147,17 +186,18 @@ class _PlannerBase:
             h.set_obstacles(self.obstacle_list)
             st = random.getstate()
             h.set_rng_state(0, st)
-            if self._trace:
-                h.enable_trace(0)
+            h.enable_trace(0)   # per-iteration (sample, nearest, what was appended): Node.path_x / path_y need it
             h.plan(strict=True)
             random.setstate(h.get_rng_state(0, st[2]))
             x, y, cost, parent = h.get_tree(0)
-            self.node_list = NodeList(x, y, cost, parent, self.path_resolution)
+            trace = h.get_trace()
+            self.node_list = NodeList(x, y, cost, parent, self.path_resolution, self.expand_dis,
+                                      _creation_records(trace, h.get_trace_kind(), len(x)))
             self.tree = (x, y, cost, parent)
             path = h.get_path(0)
             self.stats = h.get_stats()
             if self._trace:
-                self.trace = h.get_trace()
+                self.trace = trace
             if sampler == _abi.SAMPLER_SOBOL:
                 self.sobol_inter_ = h.get_sobol_index(0)
         finally:

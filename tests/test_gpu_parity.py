@@ -976,3 +976,64 @@ def test_gpu_rewire_moved_node_equals_oracle(gpu, res, rate, scene, seed):
     if r["path"] is not None:
         assert np.array_equal(out["paths"][0], r["path"])
     assert not (out["results"][2] & 16).any()
+
+
+@pytest.mark.parametrize("name", ["nodepaths_rrt01_s42", "nodepaths_rrt04_s1234_full", "nodepaths_rrt04_s7_full",
+                                  "nodepaths_rrt04_s3_early", "nodepaths_rrt04_res03_s5"])
+def test_node_path_xy_equal_the_reference(gpu, name):
+    """`Node.path_x` / `path_y` of every node (what the reference's draw_graph plots, rrt_04:1165-1167), against
+    goldens made by running the reference (oracle/gen_golden_paths.py): the mirror classes rebuild the polylines on the
+    host from the device's per-iteration trace -- extension edges (rrt_01 nodes; rrt_04 nodes appended when choose_parent
+    returned None, :1066-1067), re-steered edges under a chosen parent (:1279) and rewired edges (:1359) -- bit for bit."""
+    import random
+    import rrt_amd
+    g = np.load(util.GOLDEN + "/" + name + ".npz")
+    kw = dict(start=list(g["kw_start"]), goal=list(g["kw_goal"]), obstacle_list=[tuple(o) for o in g["obstacles"]],
+              rand_area=list(g["kw_rand_area"]), expand_dis=float(g["kw_expand_dis"]),
+              path_resolution=float(g["kw_path_resolution"]), goal_sample_rate=int(g["kw_goal_sample_rate"]),
+              max_iter=int(g["kw_max_iter"]), play_area=list(g["kw_play_area"]) if g["kw_play_area"].size else None,
+              robot_radius=float(g["kw_robot_radius"]))
+    random.seed(int(g["seed"]))
+    if "rrt01" in name:
+        rrt = rrt_amd.RRT(**kw)
+    else:
+        rrt = rrt_amd.RRTStar(sobol_sampler=False, connect_circle_dist=float(g["kw_connect_circle_dist"]),
+                              search_until_max_iter=bool(g["kw_search_until_max_iter"]), **kw)
+    path = rrt.planning(animation=False)
+    assert len(rrt.node_list) == len(g["x"])
+    assert (path is None) == (len(g["path"]) == 0) and (path is None or np.array_equal(np.array(path), g["path"]))
+    off = 0
+    for i, nd in enumerate(rrt.node_list):
+        k = int(g["path_len"][i])
+        assert nd.x == g["x"][i] and nd.y == g["y"][i], i
+        assert list(nd.path_x) == list(g["path_x"][off:off + k]) and list(nd.path_y) == list(g["path_y"][off:off + k]), \
+            "node %d (parent %d)" % (i, int(g["parent"][i]))
+        off += k
+
+
+def test_result_table_device_to_device_copy(gpu):
+    """rrtx_copy_results_device: the 16-byte records the multi-GPU gather sends, copied device -> device into a torch
+    tensor (no host round trip), equal the host table of rrtx_get_results."""
+    import importlib
+    import torch
+    import rrt_amd
+    sharding = importlib.import_module("robotics-path-planning_amd.sharding")
+    A = rrt_amd._abi
+    kw = util.c2_kwargs(600)
+    seeds = list(range(1, 33))
+    h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
+                 kw["goal_sample_rate"], kw["max_iter"], robot_radius=0.0, connect_circle_dist=50.0,
+                 search_until_max_iter=True, n_instances=len(seeds))
+    try:
+        h.set_obstacles(kw["obstacles"])
+        h.seed_instances(seeds)
+        h.plan(strict=True)
+        pc, nn, st = h.get_results()
+        t = torch.zeros((len(seeds), 2), dtype=torch.int64, device="cuda:0")
+        h.copy_results_device(t.data_ptr(), t.numel() * 8)
+        pc2, nn2, st2 = sharding.unpack_records(t.cpu().numpy())
+        assert np.array_equal(pc, pc2) and np.array_equal(nn, nn2) and np.array_equal(st, st2)
+        with pytest.raises(A.RrtxError):
+            h.copy_results_device(t.data_ptr(), 8)      # capacity too small
+    finally:
+        h.close()
