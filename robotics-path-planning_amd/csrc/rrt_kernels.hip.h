@@ -58,6 +58,7 @@ struct Inst {  // persistent per-instance state (global memory)
   double start[3], goal[3];   // x, y and (pose planners: rrt_03 / rrt_05 / rrt_06) yaw of this instance
   int32_t n, it, status, goal_node, path_n;
   int32_t first_goal;   // lowest index of a node lying exactly on the goal (-1 none yet, -2 unknown); f32-mirror path only
+  int32_t goal_dups;    // nodes with a higher index lying exactly on the goal too, while first_goal >= 0
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
       exact_rescans, alg_bytes2, nu_max, f32_fallbacks, q16_fallbacks;
   int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
@@ -1277,6 +1278,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   }
   if (c.xq) c.xq[off] = quant16(c, I->start[0], I->start[1]);
   I->first_goal = -1;
+  I->goal_dups = 0;
   if (c.elen) c.elen[off] = 0.0;
   c.cost[off] = 0.0;
   c.parent[off] = -1;
