@@ -117,7 +117,12 @@ typedef struct rrtx_stats {
   int64_t f32_fallbacks;     /* nearest queries the f32-mirror pass could not decide (repeated with the f64 pass) */
   int64_t q16_fallbacks;     /* nearest queries the 16-bit first stage could not decide on grid distances (decided by a
                                 second 16-bit pass that collects the candidates + their f64 coordinates) */
-  int64_t reserved[4];
+  /* the DOMINANT kernel alone (RRTX_ALGO_RRT_STAR with search_until_max_iter: rrt_star_kernel_v2, whose launches a
+   * rocprofv3 --kernel-trace --stats summary lists separately from the final goal-search launch; the other algorithms:
+   * their one planner kernel = the totals above) */
+  int64_t launches_main;
+  double kernel_ms_main;
+  int64_t reserved[2];
 } rrtx_stats;
 
 typedef struct rrtx_handle rrtx_handle;

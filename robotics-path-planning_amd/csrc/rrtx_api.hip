@@ -512,8 +512,8 @@ int rrtx_plan(rrtx_handle* h) {
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  double kms = 0.0;
-  int64_t launches = 0;
+  double kms = 0.0, kms_main = -1.0;
+  int64_t launches = 0, launches_main = 0;
   std::vector<Result> res(B);
   if (c.algo == RRTX_ALGO_BITSTAR) {
     // BIT*: one launch, one lane per instance (rrt_bitstar.hip.h); obstacle thresholds are size ** 2 (rrt_08:381)
@@ -572,6 +572,8 @@ int rrtx_plan(rrtx_handle* h) {
     v2_f32 = f32;
     int rc2 = launch_rrt_star_v2(h, c, B, tpb, f32, &kms, &launches);
     if (rc2) return rc2;
+    kms_main = kms;
+    launches_main = launches;
   }
   if (c.algo == RRTX_ALGO_INFORMED) {
     std::vector<double> inf(B, INFINITY);
@@ -758,6 +760,8 @@ int rrtx_plan(rrtx_handle* h) {
   }
   s.launches = launches;
   s.kernel_ms = kms;
+  s.launches_main = kms_main >= 0.0 ? launches_main : launches;
+  s.kernel_ms_main = kms_main >= 0.0 ? kms_main : kms;
   s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   h->planned = true;
   // Per-instance conditions are per-instance results: the status word of each instance carries them

@@ -1,11 +1,14 @@
 #!/bin/bash
-# Round-end measurement set (GPU box, through gpurun; RRTX_COMMIT=<short hash> in the environment):
+# Round-end measurement set (GPU box):  gpurun -- 'RRTX_COMMIT=<short hash> bash tools/measure_round.sh'
+# (the box has no .git: the hash of the commit being measured is handed in; do not edit the tree while the call is queued --
+# the snapshot is taken when the call starts)
 #   1. rocprofv3 passes of the headline bench: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)
 #      -> profiles/r2_c2_kernel_stats.csv, r2_c2_pmc_*.csv, r2_c2_traffic.json (device-code hash + commit inside)
 #   2. the driver's exact bench command under its 600 s limit -> r2_bench_c2_driver_cmd.json (reads the traffic file of 1.)
 #   3. per-phase split of the C2 iteration (diagnostic build) -> r2_c2_phase_4096x105k.txt
 #   4. C3..C6: bench line + VALU PMC pass -> r2_bench_<w>.json, r2_<w>_valu.json
 # Everything is written under gpurun_out/r2/ (merged back by gpurun); copy it into profiles/ and commit.
+export RRTX_COMMIT=${RRTX_COMMIT:-unknown}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 O=$REPO/gpurun_out/r2
 mkdir -p $O
