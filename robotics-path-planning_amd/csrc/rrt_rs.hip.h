@@ -217,7 +217,7 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
 #endif
 __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, RS_WAVES))) void rrt_rs_kernel(Ctx c, DubArgs da, int iters) {
   __shared__ ShR sh;
-  const int inst = blockIdx.x;
+  const int inst = c.inst_map ? c.inst_map[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   Inst* I = c.inst + inst;
   if (I->status & 1) return;
@@ -232,9 +232,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
   double* ndist = da.dscr + off;      // their distances (for the `.index()` collapse)
   int64_t* poff = da.poff + off;
   int32_t* plen = da.plen + off;
-  double* pool_x = da.pool_x + (int64_t)inst * da.pool_cap;
-  double* pool_y = da.pool_y + (int64_t)inst * da.pool_cap;
-  double* pool_w = da.pool_yaw + (int64_t)inst * da.pool_cap;
+  const int64_t pslot = da.pool_slot ? da.pool_slot[inst] : inst;
+  double* pool_x = da.pool_x + pslot * da.pool_cap;
+  double* pool_y = da.pool_y + pslot * da.pool_cap;
+  double* pool_w = da.pool_yaw + pslot * da.pool_cap;
   const int m = c.m;
 
   for (int i = lane; i < 624; i += TPB) sh.rng.mt[i] = I->rng.mt[i];

@@ -60,6 +60,14 @@ struct rrtx_handle {
   std::vector<void*> allocs;
   int chunk_iters = 8192;        // iterations per launch of the other planner kernels
   int32_t* inst_map = nullptr;   // device: instance ids of a partial re-plan (overflow retry)
+  // pose planners: where an instance's edge polylines live -- the handle's pool (slab = instance), or a larger pool
+  // allocated for instances that outgrew it (slab = position in that re-plan)
+  struct PoolLoc {
+    double *px = nullptr, *py = nullptr, *pyaw = nullptr;
+    int64_t cap = 0, slab = 0;
+  };
+  std::vector<PoolLoc> pool_loc;
+  int32_t* pool_slot = nullptr;  // device copy of the slab numbers of a re-plan
   int64_t stats_retried = 0;
   int v2_chunk_iters = 16384;   // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
@@ -313,7 +321,10 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     d.plain = p->algo == RRTX_ALGO_RRT_DUBINS;
     // polyline points per instance (edges replaced by rewire stay allocated; rrt_06 edges run all the way to the
     // sample at step_size spacing and are longer)
-    d.pool_cap = (p->algo == RRTX_ALGO_RS ? 160 : 128) * cap + 8192;
+    int64_t ppn = p->algo == RRTX_ALGO_RS ? 160 : 128;   // polyline points per node, on average
+    if (const char* e = getenv("RRTX_POOL_POINTS_PER_NODE"))   // test knob: a small pool exercises the re-plan below
+      if (atoi(e) > 0) ppn = atoi(e);
+    d.pool_cap = ppn * cap + 8192;
     if ((rc = dalloc(h, &d.yaw, tot))) return rc;
     if ((rc = dalloc(h, &d.poff, tot))) return rc;
     if ((rc = dalloc(h, &d.plen, tot))) return rc;
@@ -581,7 +592,16 @@ int rrtx_plan(rrtx_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));   // `inf` is a local
   }
   // on the handle's own stream: it is a non-blocking stream, work queued on the null stream is not ordered with it
-  if (is_pose_tree(c.algo)) HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
+  if (is_pose_tree(c.algo)) {
+    HIPCHK(h, hipMemsetAsync(h->da.pool_used, 0, sizeof(int64_t) * B, h->stream));
+    h->pool_loc.assign(B, rrtx_handle::PoolLoc());
+    for (int i = 0; i < B; i++) {
+      rrtx_handle::PoolLoc& pl = h->pool_loc[i];
+      pl.px = h->da.pool_x; pl.py = h->da.pool_y; pl.pyaw = h->da.pool_yaw;
+      pl.cap = h->da.pool_cap; pl.slab = i;
+    }
+    h->da.pool_slot = nullptr;
+  }
   if (const char* e = getenv("RRTX_RS_EAGER")) h->da.eager = atoi(e) != 0;
   h->da.lazy = 0;
   h->da.filter = 1;
@@ -676,6 +696,83 @@ int rrtx_plan(rrtx_handle* h) {
           h->err = "planner kernel did not converge to DONE (overflow retry)";
           return RRTX_E_STATE;
         }
+      }
+      h->stats_retried += nr;
+    }
+  }
+  // Pose planners (rrt_03 / rrt_05 / rrt_06): an instance that ran out of polyline pool (edges replaced by rewire stay
+  // allocated) is planned again, from its staged start state, with a pool four times as large -- twice if need be.
+  // Overflows of the other fixed tables (near candidates, points per edge) are not helped by that and stay reported.
+  if (is_pose_tree(c.algo) && !getenv("RRTX_NO_RETRY")) {
+    int64_t big_cap = h->da.pool_cap;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      std::vector<int32_t> redo;
+      for (int i = 0; i < B; i++)
+        if (res[i].status & RRTX_ST_OVERFLOW) redo.push_back(i);
+      if (redo.empty()) break;
+      const int nr = (int)redo.size();
+      big_cap *= 4;
+      double *bx = nullptr, *by = nullptr, *bw = nullptr;
+      const size_t bytes = sizeof(double) * (size_t)big_cap * nr;
+      if (hipMalloc((void**)&bx, bytes) != hipSuccess || hipMalloc((void**)&by, bytes) != hipSuccess ||
+          (c.algo == RRTX_ALGO_RS && hipMalloc((void**)&bw, bytes) != hipSuccess)) {
+        (void)hipGetLastError();   // no room for the larger pool: the instances keep their RRTX_ST_OVERFLOW
+        if (bx) hipFree(bx);
+        if (by) hipFree(by);
+        if (bw) hipFree(bw);
+        break;
+      }
+      h->allocs.push_back(bx);
+      h->allocs.push_back(by);
+      if (bw) h->allocs.push_back(bw);
+      int rc2;
+      if (!h->inst_map && (rc2 = dalloc(h, &h->inst_map, B))) return rc2;
+      if (!h->pool_slot && (rc2 = dalloc(h, &h->pool_slot, B))) return rc2;
+      std::vector<int32_t> slot(B, 0);
+      for (int k = 0; k < nr; k++) slot[redo[k]] = k;
+      HIPCHK(h, hipMemcpyAsync(h->inst_map, redo.data(), sizeof(int32_t) * nr, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(h->pool_slot, slot.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, h->stream));
+      for (int k = 0; k < nr; k++) {
+        HIPCHK(h, hipMemcpyAsync(c.inst + redo[k], &h->host_inst[redo[k]], sizeof(Inst), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemsetAsync(h->da.pool_used + redo[k], 0, sizeof(int64_t), h->stream));
+      }
+      Ctx cr = c;
+      cr.inst_map = h->inst_map;
+      rppd::DubArgs dr = h->da;
+      dr.pool_x = bx; dr.pool_y = by; dr.pool_yaw = bw;
+      dr.pool_cap = big_cap;
+      dr.pool_slot = h->pool_slot;
+      hipLaunchKernelGGL(rppk::rrt_init_kernel, dim3(64, nr), dim3(256), 0, h->stream, cr);
+      hipLaunchKernelGGL(rppk::rrt_root_kernel, dim3((nr + 63) / 64), dim3(64), 0, h->stream, cr, nr);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      for (int64_t guard = 0;; guard++) {
+        HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+        if (c.algo == RRTX_ALGO_RS)
+          hipLaunchKernelGGL(rppr::rrt_rs_kernel, dim3(nr), dim3(rppr::TPB), 0, h->stream, cr, dr, h->chunk_iters);
+        else
+          hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(nr), dim3(rppd::TPB), 0, h->stream, cr, dr, h->chunk_iters);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+        HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+        kms += ms;
+        launches++;
+        bool all = true;
+        for (int k = 0; k < nr; k++)
+          if (!(res[redo[k]].status & RRTX_ST_DONE)) all = false;
+        if (all) break;
+        if (guard > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
+          h->err = "planner kernel did not converge to DONE (pool retry)";
+          return RRTX_E_STATE;
+        }
+      }
+      for (int k = 0; k < nr; k++) {
+        rrtx_handle::PoolLoc& pl = h->pool_loc[redo[k]];
+        pl.px = bx; pl.py = by; pl.pyaw = bw;
+        pl.cap = big_cap; pl.slab = k;
       }
       h->stats_retried += nr;
     }
@@ -866,9 +963,9 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
     for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) {
       bx.resize(plen[nd]);
       by.resize(plen[nd]);
-      HIPCHK(h, hipMemcpy(bx.data(), h->da.pool_x + (int64_t)instance * h->da.pool_cap + poff[nd],
+      HIPCHK(h, hipMemcpy(bx.data(), h->pool_loc[instance].px + h->pool_loc[instance].slab * h->pool_loc[instance].cap + poff[nd],
                           sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
-      HIPCHK(h, hipMemcpy(by.data(), h->da.pool_y + (int64_t)instance * h->da.pool_cap + poff[nd],
+      HIPCHK(h, hipMemcpy(by.data(), h->pool_loc[instance].py + h->pool_loc[instance].slab * h->pool_loc[instance].cap + poff[nd],
                           sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
       for (int q = plen[nd] - 1; q >= 0; q--) {
         xy[2 * k] = bx[q];
@@ -977,7 +1074,7 @@ int rrtx_get_path_yaw(rrtx_handle* h, int32_t instance, double* yaw, int32_t cap
   std::vector<double> bw;
   for (int nd = I.goal_node; par[nd] >= 0; nd = par[nd]) {
     bw.resize(plen[nd]);
-    HIPCHK(h, hipMemcpy(bw.data(), h->da.pool_yaw + (int64_t)instance * h->da.pool_cap + poff[nd],
+    HIPCHK(h, hipMemcpy(bw.data(), h->pool_loc[instance].pyaw + h->pool_loc[instance].slab * h->pool_loc[instance].cap + poff[nd],
                         sizeof(double) * plen[nd], hipMemcpyDeviceToHost));
     for (int q = plen[nd] - 1; q >= 0; q--) yaw[k++] = bw[q];
   }
@@ -1007,8 +1104,9 @@ int rrtx_get_polylines(rrtx_handle* h, int32_t instance, int32_t* plen, int32_t 
   HIPCHK(h, hipMemcpy(&used, h->da.pool_used + instance, sizeof(int64_t), hipMemcpyDeviceToHost));
   std::vector<double> bx(used), by(used);
   if (used) {
-    HIPCHK(h, hipMemcpy(bx.data(), h->da.pool_x + (int64_t)instance * h->da.pool_cap, sizeof(double) * used, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(by.data(), h->da.pool_y + (int64_t)instance * h->da.pool_cap, sizeof(double) * used, hipMemcpyDeviceToHost));
+    const rrtx_handle::PoolLoc& pl = h->pool_loc[instance];
+    HIPCHK(h, hipMemcpy(bx.data(), pl.px + pl.slab * pl.cap, sizeof(double) * used, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(by.data(), pl.py + pl.slab * pl.cap, sizeof(double) * used, hipMemcpyDeviceToHost));
   }
   int64_t w = 0;
   for (int i = 0; i < n; i++) {

@@ -1037,3 +1037,38 @@ def test_result_table_device_to_device_copy(gpu):
             h.copy_results_device(t.data_ptr(), 8)      # capacity too small
     finally:
         h.close()
+
+
+def test_gpu_polyline_pool_overflow_is_replanned_with_a_larger_pool(gpu, monkeypatch):
+    """rrt_05 / rrt_06 keep every edge polyline in a per-instance pool (edges replaced by rewire stay allocated).  An
+    instance that runs out of pool is planned again with a pool four times as large, twice if need be, instead of
+    failing the batch (round-1 VERDICT: capacity limits).  RRTX_POOL_POINTS_PER_NODE shrinks the pool for the test."""
+    import oracle
+    import rrt_amd
+    g = util.load_golden(util.GOLDEN + "/rrt05_drv_s42_it500.npz")
+    seeds = [42, 43, 44, 45]
+    monkeypatch.setenv("RRTX_POOL_POINTS_PER_NODE", "4")
+    out = util.run_gpu_dubins(g, seeds, max_iter=1500)       # plan(strict=True): raises if an instance stays overflowed
+    for i, s in enumerate(seeds):
+        r = oracle.plan_dubins(g["start"], g["goal"], g["obstacles"], g["rand_area"], 1500, seed=s)
+        util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % s)
+        assert np.array_equal(out["polys"][i][1], r["poly_x"]) and np.array_equal(out["yaws"][i], r["yaw"])
+        assert (out["paths"][i] is None) == (r["path"] is None)
+        if r["path"] is not None:
+            assert np.array_equal(out["paths"][i], r["path"])
+    monkeypatch.setenv("RRTX_NO_RETRY", "1")
+    with pytest.raises(rrt_amd._abi.RrtxError):
+        util.run_gpu_dubins(g, seeds, max_iter=1500)
+    monkeypatch.delenv("RRTX_NO_RETRY")
+    g6 = util.load_golden(util.GOLDEN + "/rrt06_drv_s42_it200.npz")
+    monkeypatch.setenv("RRTX_POOL_POINTS_PER_NODE", "2")
+    bp = rrt_amd.BatchPlanner("rrt_star_reeds_shepp", [42, 43], list(g6["start"]), list(g6["goal"]),
+                              [tuple(o) for o in g6["obstacles"]], list(g6["rand_area"]), expand_dis=3.0,
+                              goal_sample_rate=10, max_iter=200, robot_radius=0.6, search_until_max_iter=True,
+                              curvature=2.0, step_size=0.1)
+    try:
+        bp.plan()
+        assert not bp.partial
+        assert np.array_equal(bp.path(0), g6["path"]) and np.array_equal(bp.yaw(0), g6["yaw"])
+    finally:
+        bp.close()
