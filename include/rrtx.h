@@ -122,7 +122,10 @@ typedef struct rrtx_stats {
    * their one planner kernel = the totals above) */
   int64_t launches_main;
   double kernel_ms_main;
-  int64_t reserved[2];
+  int64_t replanned;         /* instances planned a second time from their staged start state: a near set that outgrew its
+                                workgroup shape's table, a polyline pool that ran out, or an rrt_04 rewire that moved a
+                                node while near_inds held repeated indices (raw-list walk of the general kernel) */
+  int64_t reserved[1];
 } rrtx_stats;
 
 typedef struct rrtx_handle rrtx_handle;

@@ -49,7 +49,8 @@ class Stats(C.Structure):
                 ("exact_rescans", C.c_int64), ("total_nodes", C.c_int64), ("launches", C.c_int64),
                 ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("algorithmic_bytes_two_scan", C.c_int64),
                 ("near_unique_max", C.c_int64), ("f32_fallbacks", C.c_int64), ("q16_fallbacks", C.c_int64),
-                ("launches_main", C.c_int64), ("kernel_ms_main", C.c_double), ("reserved", C.c_int64 * 2)]
+                ("launches_main", C.c_int64), ("kernel_ms_main", C.c_double), ("replanned", C.c_int64),
+                ("reserved", C.c_int64 * 1)]
 
 
 class RrtxError(RuntimeError):

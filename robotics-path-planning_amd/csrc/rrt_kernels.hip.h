@@ -467,6 +467,19 @@ __device__ __forceinline__ int hit_at(const int32_t* hits, const SH& sh, int h) 
   }
   return hits[sh.wave_start[k] + h];
 }
+// position of that h-th hit inside hits[] (the raw-list walk of rewire stores a slot number there)
+template <class SH>
+__device__ __forceinline__ int hit_loc(const SH& sh, int h) {
+  int k = 0;
+#pragma unroll
+  for (int j = 0; j < NW - 1; j++) {
+    if (k == j && h >= sh.wave_cnt[j]) {
+      h -= sh.wave_cnt[j];
+      k = j + 1;
+    }
+  }
+  return sh.wave_start[k] + h;
+}
 
 // ---------------------------------------------------------------------------
 // Exact re-check + the `[lst.index(v) for v in lst if v <= thr]` idiom
@@ -780,6 +793,89 @@ __device__ inline void unlink_child(int32_t* parent, int32_t* first_child, int32
   else
     first_child[par] = nx;
   if (nx >= 0) prev_sib[nx] = pv;
+}
+
+// rewire (rrt_04:1357-1373) walked over the RAW near_inds list, one visit at a time, from the first visit of candidate
+// slot `es0` on.  near_inds holds `dist_list.index(d)` (:1337): nodes at equal distance collapse onto the first of them
+// and that index is listed again.  As long as no node has changed coordinates in this iteration a later visit of an index
+// is void (costs only fall while the list is walked, the edge is the same), so the candidate loop of the caller visits
+// every distinct index once.  When a rewire MOVES a node (an unsnapped steer, :1105-1110 with :1372) that no longer
+// holds: the moved node is steered to where it lies now on its next visit, and costs of its descendants -- recomputed
+// from the new position (:1375-1384) -- may rise, so that an index visited in vain before qualifies later.  From the first
+// such rewire on, every remaining entry of the raw list is therefore visited as the reference visits it, against the
+// current coordinates and costs.  dist_list itself predates the loop: the entry -> index map is taken before anything
+// moves (stored over hits[], as candidate slot numbers).  Rare (needs a distance tie in the near set and an inexact
+// path_resolution); lane 0 walks, the whole workgroup builds the map.
+__device__ inline void rewire_raw_walk(const Ctx& c, double* __restrict__ x, double* __restrict__ y,
+                                       double* __restrict__ cost, int32_t* parent, int32_t* first_child,
+                                       int32_t* next_sib, int32_t* prev_sib, int32_t* hits, int32_t* stack, int kraw,
+                                       int nu, double nx, double ny, double r2, double wx, double wy, double wcost,
+                                       int newidx, int es0, Sh& sh) {
+  const int tid = threadIdx.x;
+  for (int base = 0; base < kraw; base += TPB) {
+    const int h = base + tid;
+    int loc = -1;
+    double v = 0.0;
+    bool valid = false;
+    if (h < kraw) {
+      loc = hit_loc(sh, h);
+      const int idx = hits[loc];
+      v = rpp::py_d2(x[idx] - nx, y[idx] - ny);
+      valid = v <= r2;   // :1337
+    }
+    int slot = -1;
+    for (int cb = 0; cb < nu; cb += TPB) {
+      __syncthreads();
+      if (cb + tid < nu) {
+        const int u = sh.uidx[cb + tid];
+        sh.cval[tid] = rpp::py_d2(x[u] - nx, y[u] - ny);
+      }
+      __syncthreads();
+      const int nc = (nu - cb) < TPB ? (nu - cb) : TPB;
+      if (valid && slot < 0) {
+        for (int t = 0; t < nc; t++)
+          if (sh.cval[t] == v) {   // dist_list.index(d): the first holder of the value
+            slot = cb + t;
+            break;
+          }
+      }
+    }
+    if (h < kraw) hits[loc] = slot;   // -1: outside the ball (the pass over-collects)
+  }
+  __syncthreads();
+  if (tid == 0) {
+    bool started = false;
+    int moved = 0;
+    for (int h = 0; h < kraw; h++) {
+      const int e = hits[hit_loc(sh, h)];
+      if (e < 0) continue;
+      if (!started) {
+        if (e != es0) continue;
+        started = true;
+      }
+      const int u = sh.uidx[e];
+      const double ux = x[u], uy = y[u];
+      const double ec = wcost + rpp::py_hypot(ux - wx, uy - wy);   // calc_new_cost(new_node, near_node) :1362
+      if (!(cost[u] > ec)) continue;                               // improved_cost :1366 (strict)
+      rpp::steer(&sh.edge[0], wx, wy, ux, uy, rpp::dinf(), c.res);   // :1359
+      bool ok = rpp::in_play_area(c.has_play, c.play_area, sh.edge[0].ex, sh.edge[0].ey);
+      for (int k = 0; k < c.m && ok; k++)
+        if (rpp::edge_hits_obstacle(sh.edge[0], sh.ox[k], sh.oy[k], sh.othr[k])) ok = false;
+      if (!ok) continue;
+      unlink_child(parent, first_child, next_sib, prev_sib, u);   // :1369-1371 (also when it already hangs under newidx)
+      if (sh.edge[0].ex != ux || sh.edge[0].ey != uy) {
+        x[u] = sh.edge[0].ex;   // node_list[i] = edge_node :1372
+        y[u] = sh.edge[0].ey;
+        moved = 1;
+      }
+      cost[u] = ec;
+      link_child(parent, first_child, next_sib, prev_sib, u, newidx);
+      sh.flag++;
+      sh.sel += propagate(x, y, cost, first_child, next_sib, stack, u);   // :1373
+    }
+    if (moved) sh.nvalid = 1;
+  }
+  __syncthreads();
 }
 
 // generate_final_course (rrt_04:1117-1125) + get_path_length (:1391-1399), lane 0.
@@ -1101,6 +1197,7 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
         __syncthreads();
         PH(8);
         // list order; later entries see costs updated by earlier successes (:1357-1373)
+        int raw_from = -1;
         for (int e0 = 0; e0 < nu;) {
           int cand = 0x7fffffff;
           for (int e = e0 + tid; e < nu; e += TPB) {
@@ -1112,6 +1209,12 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
           const int es = block_min_int(cand, sh);
           if (es == 0x7fffffff) break;
           const int u = sh.uidx[es];
+          if (!(sh.usafe[es] & 4) && nvalid > nu) {
+            // this rewire moves its node and near_inds has repeated entries (distance ties, :1337): from here on the
+            // raw list is walked visit by visit, as the reference does (rewire_raw_walk)
+            raw_from = es;
+            break;
+          }
           if (tid == 0) {
             unlink_child(parent, first_child, next_sib, prev_sib, u);
             if (!(sh.usafe[es] & 4)) {
@@ -1120,9 +1223,6 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
               x[u] = sh.edge[0].ex;
               y[u] = sh.edge[0].ey;
               sh.nvalid = 1;
-              // the moved node listed again in near_inds (distance tie, :1337) would be re-steered by the
-              // reference's second visit: not restated here -> stop loudly (RRTX_ST_UNSUPPORTED), see v2 body
-              if (nvalid > nu) sh.overflow = 2;
             }
             cost[u] = sh.uval[es];
             link_child(parent, first_child, next_sib, prev_sib, u, newidx);
@@ -1140,6 +1240,9 @@ __global__ __launch_bounds__(TPB, 4) void rrt_plan_kernel(Ctx c, int iters) {
           __syncthreads();
           e0 = es + 1;
         }
+        if (raw_from >= 0)
+          rewire_raw_walk(c, x, y, cost, parent, first_child, next_sib, prev_sib, hits, stack, kraw, nu, nx, ny, r2, wx,
+                          wy, wcost, newidx, raw_from, sh);
         if (tid == 0) {
           // append :1065
           x[newidx] = wx;

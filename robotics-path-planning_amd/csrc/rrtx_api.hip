@@ -481,6 +481,7 @@ int rrtx_plan(rrtx_handle* h) {
   HIPCHK(h, hipDeviceSynchronize());   // uploads made through the null stream (obstacles, tables) are complete
   Ctx& c = h->c;
   const int B = h->n_inst;
+  h->stats_retried = 0;
   // f32-mirror margin = 2^-20 * the largest coordinate magnitude a node or sample is assumed to have (see scan2f);
   // rrt_07's informed samples are not clipped to the sampling square, so twice that (the kernel checks and falls back)
   {
@@ -651,14 +652,8 @@ int rrtx_plan(rrtx_handle* h) {
   // candidates), and finally by the general kernel (512).  Same results as a first plan on that shape: every shape
   // runs the same statements.
   if (use_v2 && !getenv("RRTX_NO_RETRY")) {
-    int shape = v2_tpb;   // 0 = general kernel
-    for (;;) {
-      std::vector<int32_t> redo;
-      for (int i = 0; i < B; i++)
-        if (res[i].status & RRTX_ST_OVERFLOW) redo.push_back(i);
-      if (redo.empty() || shape == 0) break;
-      shape = shape == 64 ? 128 : shape == 128 ? 256 : 0;
-      if (shape && c.m > v2_shape_maxobs(shape)) continue;
+    // plans the instances `redo` again: shape = workgroup shape of the iteration kernel, 0 = general kernel alone
+    auto replan = [&](const std::vector<int32_t>& redo, int shape) -> int {
       const int nr = (int)redo.size();
       if (!h->inst_map) {
         int rc2;
@@ -693,11 +688,32 @@ int rrtx_plan(rrtx_handle* h) {
           if (!(res[redo[k]].status & RRTX_ST_DONE)) all = false;
         if (all) break;
         if (guard > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
-          h->err = "planner kernel did not converge to DONE (overflow retry)";
+          h->err = "planner kernel did not converge to DONE (retry)";
           return RRTX_E_STATE;
         }
       }
       h->stats_retried += nr;
+      return RRTX_OK;
+    };
+    int shape = v2_tpb;   // 0 = general kernel
+    for (;;) {
+      std::vector<int32_t> redo;
+      for (int i = 0; i < B; i++)
+        if (res[i].status & RRTX_ST_OVERFLOW) redo.push_back(i);
+      if (redo.empty() || shape == 0) break;
+      shape = shape == 64 ? 128 : shape == 128 ? 256 : 0;
+      if (shape && c.m > v2_shape_maxobs(shape)) continue;
+      int rc2 = replan(redo, shape);
+      if (rc2) return rc2;
+    }
+    // rewire moved a node while near_inds had repeated entries (rrt_04:1337 with :1372): the iteration kernel does not
+    // walk the raw list (RRTX_ST_UNSUPPORTED in its status word), the general kernel does (rppk::rewire_raw_walk)
+    std::vector<int32_t> redo;
+    for (int i = 0; i < B; i++)
+      if (res[i].status & RRTX_ST_UNSUPPORTED) redo.push_back(i);
+    if (!redo.empty()) {
+      int rc2 = replan(redo, 0);
+      if (rc2) return rc2;
     }
   }
   // Pose planners (rrt_03 / rrt_05 / rrt_06): an instance that ran out of polyline pool (edges replaced by rewire stay
@@ -859,6 +875,7 @@ int rrtx_plan(rrtx_handle* h) {
   s.kernel_ms = kms;
   s.launches_main = kms_main >= 0.0 ? launches_main : launches;
   s.kernel_ms_main = kms_main >= 0.0 ? kms_main : kms;
+  s.replanned = h->stats_retried;
   s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   h->planned = true;
   // Per-instance conditions are per-instance results: the status word of each instance carries them

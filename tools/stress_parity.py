@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stress parity (GPU box): many seeds per planner, GPU trees vs the golden-pinned oracle, bit for bit.
-Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 runs that block only)"""
+Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 / STRESS_ONLY=moved run that block only)"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -60,6 +60,12 @@ def o04(a):
     return r["x"], r["y"], r["cost"], r["parent"]
 
 
+def o04x(a):
+    sd, kw = a
+    r = util.run_oracle(kw, sd, exact_pow=True)
+    return r["x"], r["y"], r["cost"], r["parent"]
+
+
 def o07(a):
     import oracle
     sd, kw = a
@@ -90,15 +96,29 @@ if __name__ == "__main__":
     with ProcessPoolExecutor(max_workers=14) as ex:
         seeds = list(range(1, CNT + 1))
         # rrt_06 (lazy candidate order on the device vs the oracle steering every candidate)
-        for nm, upd in (("driver, 750 it", {}), ("driver, 2000 it", {"max_iter": 2000}),
-                        ("driver, early exit", {"search_until_max_iter": 0, "max_iter": 1500}),
-                        ("curvature 1, step 0.2, radius 0, goal yaw 1.2, 1000 it",
-                         {"curvature": 1.0, "step_size": 0.2, "robot_radius": 0.0, "max_iter": 1000,
-                          "goal": np.array([10.0, 9.0, 1.2])})):
+        rs_cases = (("driver, 750 it", {}), ("driver, 2000 it", {"max_iter": 2000}),
+                    ("driver, early exit", {"search_until_max_iter": 0, "max_iter": 1500}),
+                    ("curvature 1, step 0.2, radius 0, goal yaw 1.2, 1000 it",
+                     {"curvature": 1.0, "step_size": 0.2, "robot_radius": 0.0, "max_iter": 1000,
+                      "goal": np.array([10.0, 9.0, 1.2])}))
+        for nm, upd in (() if os.environ.get("STRESS_ONLY") == "moved" else rs_cases):
             g = dict(G06); g.update(upd)
             out = util.run_gpu_rrt_rs(g, seeds)
             total += compare("rrt_06 " + nm, out["trees"], list(ex.map(o06, [(s, g) for s in seeds])))
         if os.environ.get("STRESS_ONLY") == "rrt06":
+            print("TOTAL mismatches", total)
+            sys.exit(1 if total else 0)
+        # rrt_04 with inexact path resolutions: rewires that MOVE their node (rrt_04:1372), many of them in iterations
+        # whose near_inds repeats indices (goal duplicates) -> raw-list walk of the general kernel (`replanned`)
+        for res, rate, it in ((0.05, 95, 400), (0.05, 20, 400), (0.1, 60, 400), (0.3, 95, 600)):
+            kwm = dict(util.C2)
+            kwm.update(start=[0, 0], goal=[6, 8], rand_area=[-2, 12], obstacles=[(3, 3, 1)], expand_dis=3.0,
+                       path_resolution=res, goal_sample_rate=rate, connect_circle_dist=50.0, max_iter=it, robot_radius=0.0)
+            sdm = seeds + ([19507] if (res, rate) == (0.05, 20) else [])
+            out = util.run_gpu_batch(kwm, sdm)
+            total += compare("rrt_04 moved nodes res %g rate %d (replanned %d)" % (res, rate, out["stats"]["replanned"]),
+                             out["trees"], list(ex.map(o04x, [(s, kwm) for s in sdm])))
+        if os.environ.get("STRESS_ONLY") == "moved":
             print("TOTAL mismatches", total)
             sys.exit(1 if total else 0)
         # rrt_05
