@@ -24,7 +24,7 @@ h.seed_instances(list(range(1, B + 1)))
 h.plan()
 s = h.get_stats()
 ph = h.get_phase_cycles()
-names = {0: "sample", 1: "nearest scan", 2: "ext edge (cooperative)", 4: "near scan", 5: "exact+dedup",
+names = {0: "sample", 1: "nearest scan", 2: "ext edge (cooperative)", 3: "choose: costs + ranking", 4: "near scan", 5: "exact+dedup",
          6: "choose: lane edges + argmin", 7: "winner edge + append", 8: "rewire: lane edges", 9: "rewire: sequential",
          15: "loop", 10: "  (candidates: prepare, both stages)", 11: "  (candidates: prefix sum)",
          12: "  (candidates: points)"}
