@@ -57,8 +57,11 @@ enum { RRTX_SAMPLER_MT = 0,     /* get_random_node        rrt_04:1132-1139 */
 
 /* per-instance status bits (rrtx_get_results) */
 enum { RRTX_ST_DONE = 1, RRTX_ST_PATH = 2, RRTX_ST_OVERFLOW = 4, RRTX_ST_PATH_TRUNC = 8,
-       RRTX_ST_UNSUPPORTED = 16 /* a reference code path the device kernel does not restate was reached (see
-                                   rrtx_last_error); the instance stops there instead of continuing differently */,
+       RRTX_ST_UNSUPPORTED = 16 /* a reference code path the device kernel does not restate was reached; the instance
+                                   stops there instead of continuing differently.  No planner sets it in a result any
+                                   more: the one such path (rrt_04 rewire visiting a MOVED node again, :1337 with :1372)
+                                   is walked by the general kernel, to which rrtx_plan hands such instances over
+                                   (rrtx_stats.replanned); kept as a guard */,
        RRTX_ST_REF_RAISES = 32  /* RRTX_ALGO_RS: the reference raises here (ZeroDivisionError :1183/:1207 or ValueError from
                                    math.acos/asin) inside reeds_shepp_path_planning; the instance stops, no path */ };
 
