@@ -178,6 +178,32 @@ def main():
     n = "rrt04_c2_sobol_s4_it1500"
     if want(n):
         run_rrt04(m04, n, sobol=1, until_max=True, seed=4, max_iter=1500, **c2)
+    # edge cases (empty / degenerate inputs), the reference run on each: driver scenario with one thing changed
+    edge = dict(drv)
+    edge["max_iter"] = 300
+    for tag, upd in (("noobst", dict(obstacles=[])),                       # empty obstacle list
+                     ("iter0", dict(max_iter=0)), ("iter1", dict(max_iter=1)),
+                     ("startblocked", dict(start=[5.0, 5.0])),               # start inside a circle: nothing ever extends
+                     ("goalinside", dict(goal=[3.0, 8.0])),                  # goal inside a circle: no path
+                     ("rate100", dict(goal_sample_rate=100)), ("rate0", dict(goal_sample_rate=0)),
+                     ("bigstep", dict(expand_dis=30.0)),                     # every extension reaches its sample
+                     ("substep", dict(expand_dis=0.05)),                     # expand_dis < path_resolution: floor() = 0
+                     ("startgoal", dict(goal=[0.0, 0.0])),                   # start == goal
+                     ("revarea", dict(rand_area=[15, -2])),                  # random.uniform(a, b) with a > b
+                     ("bigrobot", dict(robot_radius=2.5, play_area=None)),
+                     ("tinyplay", dict(play_area=[-0.5, 0.5, -0.5, 0.5]))):  # play area around the start only
+        for until in (1, 0):
+            n = "rrt04_edge_%s_%s" % (tag, "full" if until else "early")
+            if want(n):
+                d2 = dict(edge)
+                d2.update(upd)
+                run_rrt04(m04, n, sobol=0, until_max=bool(until), seed=3, **d2)
+        n = "rrt01_edge_%s" % tag
+        if want(n) and tag != "tinyplay":
+            d2 = dict(edge)
+            d2.update(upd)
+            d2["play_area"] = None
+            run_rrt04(m01, n, sobol=0, until_max=False, seed=3, algo="rrt", **d2)
     # rrt_01 driver scenario (rrt_01:354-391), seeds 0..15 (config C1)
     d1 = dict(drv)
     d1["play_area"] = None
@@ -233,6 +259,11 @@ def run_rrt07(mod, name, obstacles, start, goal, rand_area, expand_dis, goal_sam
     dt = time.time() - t0
     x, y, cost, parent = tree_arrays(rrt.node_list, int_parent=True)
     state = random.getstate()
+    if "c" not in cm:   # max_iter = 0: the loop never samples, so the hook never saw the ellipse terms (unused in that
+        import oracle    # run); stored from the numpy restatement that the other rrt_07 goldens pin
+        cm.update(c=oracle.rotation_to_world(list(start), list(goal)),
+                  c_min=math.hypot(start[0] - goal[0], start[1] - goal[1]),
+                  x_center=np.array([[(start[0] + goal[0]) / 2.0], [(start[1] + goal[1]) / 2.0], [0]]))
     out = dict(
         algo="informed", seed=seed, obstacles=np.array(obstacles, dtype=np.float64),
         start=np.array(start, dtype=np.float64), goal=np.array(goal, dtype=np.float64),
@@ -269,6 +300,11 @@ def main07(only=""):
                goal_sample_rate=10)
     for seed, it, sob in ((3, 700, 1), (4, 700, 0)):
         jobs.append(("rrt07_c3near_%s_s%d_it%d" % ("sobol" if sob else "mt", seed, it), dict(c3b, max_iter=it, sobol=sob, seed=seed)))
+    # edge cases: the driver scenario with one thing changed
+    for tag, upd in (("noobst", dict(obstacles=[])), ("iter0", dict(max_iter=0)), ("iter1", dict(max_iter=1)),
+                     ("startblocked", dict(start=[5.0, 5.0])), ("goalinside", dict(goal=[3.0, 8.0])),
+                     ("rate100", dict(goal_sample_rate=100))):   # start == goal: the reference divides by c_min = 0 (:1058)
+        jobs.append(("rrt07_edge_%s" % tag, dict(dict(drv, max_iter=300, sobol=0, seed=3), **upd)))
     for n, kw in jobs:
         if n.startswith(only):
             run_rrt07(m07, n, **kw)
@@ -344,6 +380,14 @@ def main05(only=""):
         n = "rrt05_drv_s%d_it%d" % (seed, it)
         if n.startswith(only):
             run_rrt05(m05, n, max_iter=it, seed=seed, **drv)
+    for tag, upd in (("noobst", dict(obstacles=[])), ("iter0", dict(max_iter=0)), ("iter1", dict(max_iter=1)),
+                     ("startblocked", dict(start=[5.0, 5.0, 0.0])), ("goalinside", dict(goal=[3.0, 8.0, 0.0])),
+                     ("startgoal", dict(goal=[0.0, 0.0, 0.0]))):
+        n = "rrt05_edge_%s" % tag
+        if n.startswith(only):
+            run_rrt05(m05, n, **dict(dict(drv, max_iter=200, seed=3), **upd))
+    if only.startswith("rrt05_edge") or only.startswith("rrt05_drv"):
+        return
     # Dubins primitive known-answer vectors: plan_dubins_path on random poses (no planner around it)
     rng = random.Random(5)
     rows = []
@@ -566,6 +610,11 @@ def main06(only=""):
         n = "rrt06_drv_s%d_it%d%s" % (seed, it, "" if um else "_early")
         if n.startswith(only):
             run_rrt06(m06, n, max_iter=it, seed=seed, until_max=um, **drv)
+    for tag, upd in (("noobst", dict(obstacles=[])), ("iter0", dict(max_iter=0)), ("iter1", dict(max_iter=1)),
+                     ("startblocked", dict(start=[5.0, 5.0, 0.0])), ("goalinside", dict(goal=[3.0, 8.0, 0.0]))):
+        n = "rrt06_edge_%s" % tag
+        if n.startswith(only):
+            run_rrt06(m06, n, **dict(dict(drv, max_iter=150, seed=3, until_max=True), **upd))
 
 
 def main06_kat(only=""):

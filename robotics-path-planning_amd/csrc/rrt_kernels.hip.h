@@ -1380,7 +1380,8 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
     c.yf[off] = (float)I->start[1];
   }
   if (c.xq) c.xq[off] = quant16(c, I->start[0], I->start[1]);
-  I->first_goal = -1;
+  // a start that lies exactly on the goal is the first such node (every goal sample then duplicates the ROOT)
+  I->first_goal = (I->start[0] == I->goal[0] && I->start[1] == I->goal[1]) ? 0 : -1;
   I->goal_dups = 0;
   if (c.elen) c.elen[off] = 0.0;
   c.cost[off] = 0.0;
