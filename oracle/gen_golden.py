@@ -729,3 +729,11 @@ def main08(only=""):
         n = "rrt08_s%d_it%d" % (seed, it)
         if n.startswith(only):
             run_rrt08(m08, n, obst, st, gl, [-2, 15], it, seed)
+    for tag, ob, it, st, gl in (("noobst", [], 60, [-1.0, 0.0], [3.0, 8.0]), ("iter1", obst, 1, [-1.0, 0.0], [3.0, 8.0]),
+                                ("iter0", obst, 0, [-1.0, 0.0], [3.0, 8.0]),
+                                # a start inside a circle is NOT here: plan() never returns (its `continue`s skip the
+                                # iteration counter, :283); tests/test_gpu_parity.py checks the device ends it as OVERFLOW
+                                ("goalinside", obst, 40, [-1.0, 0.0], [7.0, 9.0])):
+        n = "rrt08_edge_%s" % tag
+        if n.startswith(only):
+            run_rrt08(m08, n, ob, st, gl, [-2, 15], it, 3)

@@ -728,6 +728,72 @@ def test_gpu_bitstar_batch_c4_style_equals_oracle(gpu, monkeypatch, kernel, n):
         assert (p is None and len(r["path"]) == 0) or np.array_equal(p, r["path"]), i
 
 
+def test_gpu_input_limits(gpu):
+    """Maximum sizes and refused inputs: 256 circles (the device tile's capacity) plan as the oracle does, in the
+    iteration kernel's widest shape and in the general kernel; 257 are refused by rrtx_set_obstacles, as are a handle of
+    0 instances, a negative max_iter and an instance number outside the batch -- errors, never a clipped input."""
+    import rrt_amd
+    A = rrt_amd._abi
+    kw = util.c2_kwargs(1500, m=256, map_seed=13)
+    r = util.run_oracle(kw, 5, exact_pow=True)
+    for until in (1, 0):
+        kw2 = dict(kw, search_until_max_iter=until)
+        ro = r if until else util.run_oracle(kw2, 5, exact_pow=True)
+        out = util.run_gpu_batch(kw2, [5, 6])
+        util.assert_tree_equal(out["trees"][0], (ro["x"], ro["y"], ro["cost"], ro["parent"]), "256 obstacles, until_max %d" % until)
+    kw3 = util.c2_kwargs(10, m=257, map_seed=13)
+    with pytest.raises(A.RrtxError):
+        util.run_gpu_batch(kw3, [5])
+    common = ([2.0, 2.0], [98.0, 98.0], [0, 100], 2.0, 0.25, 5)
+    with pytest.raises(A.RrtxError):
+        A.Handle(A.ALGO_RRT_STAR, *common, 100, n_instances=0)
+    with pytest.raises(A.RrtxError):
+        A.Handle(A.ALGO_RRT_STAR, *common, -1, n_instances=1)
+    h = A.Handle(A.ALGO_RRT_STAR, *common, 100, n_instances=2)
+    try:
+        with pytest.raises(A.RrtxError):
+            h.set_instance(2, [2.0, 2.0], [98.0, 98.0])
+        with pytest.raises(A.RrtxError):
+            h.get_tree(0)   # nothing planned yet
+    finally:
+        h.close()
+
+
+@pytest.mark.timeout(180)
+def test_gpu_bitstar_start_inside_an_obstacle_ends_as_overflow(gpu):
+    """A start inside a circle: every connect() of rrt_08's plan() fails, its `continue` (:283) skips the iteration
+    counter and the reference loops for ever, sampling 100 more points each time the queues run dry (measured: no
+    return within 20 minutes).  The device must not: the instance fills its sample slab and stops with
+    RRTX_ST_OVERFLOW (the oracle ends the same way), the call returns RRTX_PARTIAL, and the other instance of the
+    batch is complete and equal to the oracle."""
+    import oracle
+    import rrt_amd
+    A = rrt_amd._abi
+    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+    starts, goals, seeds = [[7.0, 5.0], [-1.0, 0.0]], [[3.0, 8.0], [3.0, 8.0]], [3, 42]
+    with pytest.raises(RuntimeError):
+        oracle.plan_bitstar(starts[0], goals[0], obst, [-2, 15], 40, seed=3)
+    c_min, c = rrt_amd.bitstar_rotation(starts[0], goals[0])
+    h = A.Handle(A.ALGO_BITSTAR, starts[0], goals[0], [-2.0, 15.0], 2.0, 1.0, 0, 40, n_instances=2,
+                 informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+    try:
+        h.set_obstacles(obst)
+        h.seed_instances(seeds)
+        for i in range(2):
+            cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])
+            h.set_instance(i, starts[i], goals[i])
+            h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        h.plan(strict=False)
+        st = h.get_results()[2]
+        assert st[0] & A.ST_OVERFLOW and not (st[1] & A.ST_FAILED)
+        r = oracle.plan_bitstar(starts[1], goals[1], obst, [-2, 15], 40, seed=42)
+        x, y, cost, parent = h.get_tree(1)
+        gx, gy = _bit_coords(r["vertex_ids"])
+        assert np.array_equal(x, gx) and np.array_equal(y, gy) and np.array_equal(cost, r["g_scores"])
+    finally:
+        h.close()
+
+
 def test_bitstar_host_class_drop_in(gpu):
     import random
     import rrt_amd
