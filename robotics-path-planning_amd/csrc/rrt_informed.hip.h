@@ -34,6 +34,7 @@ constexpr int NUI_SMALL = 512, NUI_LARGE = 2048;
 
 template <int NUI>
 struct ShIT {
+  static constexpr int kTPB = TPB, kNW = NW;   // shape of the rppk:: helpers
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   double orad[MAX_OBS];   // obstacle radius (sqrt of the threshold), rounded up: the cheap reject test of choose_parent
@@ -145,6 +146,41 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
   }
 }
 
+// check_collision (rrt_07:1271-1276) of the candidate slots listed in sh.cflag[0..nt) (nt <= TPB): lane t derives
+// (theta, end point) of its candidate exactly as choose_parent :1117-1119 / rewire :1242-1244 do -- both arrive at the same
+// (theta, d) -- then a wave takes a candidate, its lanes the obstacles.  The exact segment distance (:1249-1261) is
+// evaluated only for obstacles that can touch the segment: dist(p, segment) >= |p - midpoint| - half length, so
+// |p - mid| > half length + radius (with 1e-9 of slack against the roundings of this test) leaves
+// `distance**2 <= size**2` false whatever the exact form returns.  Result in sh.ufree[e] (1 free, 0 blocked).
+template <int NUI>
+__device__ __forceinline__ void test_candidates(const Ctx& c, ShIT<NUI>& sh, int nt, double nx, double ny) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid < nt) {
+    const int e = sh.cflag[tid];
+    const double dx = nx - sh.ux[e], dy = ny - sh.uy[e];
+    const double th = rpp_glibc_atan2(dy, dx);
+    const double d = sh.ud[e];
+    sh.uex[e] = sh.ux[e] + rpp_glibc_cos(th) * d;
+    sh.uey[e] = sh.uy[e] + rpp_glibc_sin(th) * d;
+  }
+  __syncthreads();
+  for (int t = w; t < nt; t += NW) {
+    const int e = sh.cflag[t];
+    const double vx = sh.ux[e], vy = sh.uy[e], ex2 = sh.uex[e], ey2 = sh.uey[e];
+    const double mx = 0.5 * (vx + ex2), my = 0.5 * (vy + ey2), hl = 0.5 * sh.ud[e] * (1.0 + 1e-12);
+    bool hit = false;
+    for (int k = lane; k < c.m; k += 64) {
+      const double ddx = sh.ox[k] - mx, ddy = sh.oy[k] - my, tt = hl + sh.orad[k];
+      if (ddx * ddx + ddy * ddy <= tt * tt * (1.0 + 1e-9)) {
+        if (seg_dist2(vx, vy, ex2, ey2, sh.ox[k], sh.oy[k]) <= sh.othr[k]) hit = true;
+      }
+    }
+    const bool any = __ballot(hit) != 0ull;
+    if (lane == 0) sh.ufree[e] = any ? 0 : 1;
+  }
+  __syncthreads();
+}
+
 // per instance -- rot: C[0][0], C[0][1], C[1][0], C[1][1]; xc: ellipse centre; c_min2 = c_min**2 (host libm)
 struct InformedArgs {
   double rot[4];
@@ -154,7 +190,7 @@ struct InformedArgs {
 
 template <int NUI, int WPS>
 __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const InformedArgs* __restrict__ per_inst,
-                                                                double* cbest_io, int iters) {
+                                                                double* cbest_io, int iters, int eager) {
   __shared__ ShIT<NUI> sh;
   const int inst = c.inst_map ? c.inst_map[blockIdx.x] : blockIdx.x;
   const InformedArgs ia = per_inst[inst];   // rotation, centre and c_min**2 of THIS instance's start / goal pair
@@ -330,6 +366,111 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       s_ab += 48 * (int64_t)nu + 28;
       s_ab2 += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
       PH(4);
+      if (!eager) {
+        // ---------------- choose_parent :1110-1135, cheapest first.  A candidate's cost `cost_i + d` (:1120) does not
+        // depend on its collision test, so the candidates are ranked by (cost, list position) and tested in growing
+        // batches (4, 8, 16 ...): the first free one in rank order IS the reference's `min(d_list)` / `.index` pick
+        // (:1125-1126); later ones are never tested.  atan2 / cos / sin (:1118, :1273-1274) are evaluated for tested
+        // candidates only.  ufree: -1 not tested, 0 blocked, 1 free.  The rank lives in uey[] until the slot is tested.
+        for (int e = tid; e < nu; e += TPB) {
+          sh.ud[e] = rpp::py_hypot(nx - sh.ux[e], ny - sh.uy[e]);
+          sh.ufree[e] = -1;
+        }
+        __syncthreads();
+        for (int e = tid; e < nu; e += TPB) {
+          const double ce = sh.ucost[e] + sh.ud[e];
+          int rk = 0;
+#pragma unroll 4
+          for (int j = 0; j < nu; j++) {
+            const double cj = sh.ucost[j] + sh.ud[j];
+            rk += (cj < ce || (cj == ce && j < e)) ? 1 : 0;
+          }
+          sh.uey[e] = (double)rk;
+        }
+        __syncthreads();
+        int tested = 0, found = 0;
+        for (int base = 0, bsz = 4; base < nu && !found; base += bsz, bsz = bsz < TPB / 2 ? 2 * bsz : TPB) {
+          const int na = (nu - base < bsz) ? nu - base : bsz;
+          if (tid == 0) sh.flag = 0x7fffffff;
+          for (int e = tid; e < nu; e += TPB) {
+            if (sh.ufree[e] >= 0) continue;   // tested in an earlier batch (its uey[] is an end point now)
+            const int rk = (int)sh.uey[e];
+            if (rk >= base && rk < base + na) sh.cflag[rk - base] = e;
+          }
+          __syncthreads();
+          test_candidates(c, sh, na, nx, ny);   // overwrites uey[] of the tested slots only: their rank is in cflag order
+          tested += na;
+          if (tid < na && sh.ufree[sh.cflag[tid]] == 1) atomicMin(&sh.flag, tid);
+          __syncthreads();
+          const int t = sh.flag;
+          if (t != 0x7fffffff) {
+            found = 1;
+            if (tid == 0) {
+              const int e = sh.cflag[t];
+              sh.ncost = sh.ucost[e] + sh.ud[e];   // :1132-1133
+              sh.npar = sh.uidx[e];
+            }
+          }
+          __syncthreads();
+        }
+        s_eu += tested;
+        s_er += nvalid;
+        const double ncost = sh.ncost;
+        if (rpp::dabs(nx) > fmax || rpp::dabs(ny) > fmax) f32_ok = 0;   // outside the magnitude the margin covers
+        PH(6);
+        // ---------------- append :1091, rewire :1232-1246: only a candidate with `near_node.cost > s_cost` (:1241) gets a
+        // collision test (:1244); nothing the loop writes is read by a later candidate (no propagation in rrt_07), so
+        // the candidates are independent.  Those not tested by choose_parent are tested now.
+        if (tid == 0) {
+          x[n] = nx;
+          y[n] = ny;
+          if (xf) {
+            xf[n] = (float)nx;
+            yf[n] = (float)ny;
+          }
+          cost[n] = ncost;
+          parent[n] = sh.npar;
+          sh.nrw = 0;
+          sh.flag = 0;
+        }
+        __syncthreads();
+        int extra = 0;
+        for (int e0 = 0; e0 < nu; e0 += TPB) {
+          const int e = e0 + tid;
+          const bool need = e < nu && sh.ucost[e] > ncost + sh.ud[e] && sh.ufree[e] < 0;
+          if (need) sh.cflag[atomicAdd(&sh.flag, 1)] = e;
+          __syncthreads();
+          const int nt = sh.flag;
+          __syncthreads();
+          if (nt > 0) {
+            test_candidates(c, sh, nt, nx, ny);
+            extra += nt;
+            if (tid == 0) sh.flag = 0;
+            __syncthreads();
+          }
+        }
+        int my_rw = 0, my_chk = 0;
+        for (int e = tid; e < nu; e += TPB) {
+          const double s_cost = ncost + sh.ud[e];
+          if (sh.ucost[e] > s_cost) {          // near_node.cost > s_cost :1241
+            my_chk++;
+            if (sh.ufree[e] == 1) {            // check_collision(near_node, theta, d) :1244
+              const int u = sh.uidx[e];
+              parent[u] = n;
+              cost[u] = s_cost;
+              my_rw++;
+            }
+          }
+        }
+        if (my_rw) atomicAdd(&sh.nrw, my_rw);
+        if (my_chk) atomicAdd(&sh.nvalid, my_chk);   // nvalid reused: rewire collision tests the reference makes
+        n++;
+        __syncthreads();
+        s_rw += sh.nrw;
+        s_eu += extra;
+        s_er += sh.nvalid - nvalid;
+        PH(9);
+      } else {
       // ---------------- choose_parent :1110-1135 : (d, theta, end point) per candidate, then candidate x obstacle
       for (int e = tid; e < nu; e += TPB) {
         const double dx = nx - sh.ux[e], dy = ny - sh.uy[e];
@@ -417,6 +558,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       s_eu += sh.nvalid - nvalid;
       s_er += sh.nvalid - nvalid;
       PH(9);
+      }   // eager
       // ---------------- goal bookkeeping :1094-1103
       if (tid == 0) {
         sh.flag = (rpp::py_hypot(nx - gx, ny - gy) < E) ? 1 : 0;   // is_near_goal :1226-1230 (strict)

@@ -115,7 +115,7 @@ __device__ __forceinline__ uint32_t quant16(const Ctx& c, double px, double py) 
 }
 
 struct Sh {
-  static constexpr int kNU = NU_MAX;
+  static constexpr int kNU = NU_MAX, kTPB = TPB, kNW = NW;   // the templated helpers below take their shape from the LDS struct
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   rpp::Edge edge[EB];
@@ -177,7 +177,7 @@ __device__ __forceinline__ void block_argmin(double best, int bidx, double secon
   double gb = sh.red_best[0];
   int gi = sh.red_idx[0];
 #pragma unroll
-  for (int k = 1; k < NW; k++) {
+  for (int k = 1; k < SH::kNW; k++) {
     double ob = sh.red_best[k];
     int oi = sh.red_idx[k];
     bool take = (ob < gb) || (ob == gb && oi < gi);
@@ -186,7 +186,7 @@ __device__ __forceinline__ void block_argmin(double best, int bidx, double secon
   }
   double gs = rpp::dinf();
 #pragma unroll
-  for (int k = 0; k < NW; k++) {
+  for (int k = 0; k < SH::kNW; k++) {
     double c = (sh.red_idx[k] == gi) ? sh.red_second[k] : sh.red_best[k];
     gs = c < gs ? c : gs;
   }
@@ -204,7 +204,7 @@ template <class SH>
 __device__ __forceinline__ void scan_nearest(const double* __restrict__ x, const double* __restrict__ y, int n,
                                              double qx, double qy, SH& sh, int& ni, double& gbest, double& gsecond) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
+  const int per = roundup_i((n + SH::kNW - 1) / SH::kNW, WAVE_STRIDE);
   const int ws = w * per;
   const int we = ws + per;
   double best = rpp::dinf(), second = rpp::dinf();
@@ -250,7 +250,7 @@ template <class SH>
 __device__ __forceinline__ int scan_hits(const double* __restrict__ x, const double* __restrict__ y, int n, double qx,
                                          double qy, double thr, int32_t* __restrict__ hits, SH& sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE);
+  const int per = roundup_i((n + SH::kNW - 1) / SH::kNW, WAVE_STRIDE);
   const int ws = w * per;
   const int we = ws + per;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -286,7 +286,7 @@ __device__ __forceinline__ int scan_hits(const double* __restrict__ x, const dou
   __syncthreads();
   int total = 0;
 #pragma unroll
-  for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
+  for (int k = 0; k < SH::kNW; k++) total += sh.wave_cnt[k];
   return total;
 }
 
@@ -301,7 +301,7 @@ template <class SH>
 __device__ __forceinline__ void scan_nearest_f32(const float* __restrict__ xf, const float* __restrict__ yf, int n,
                                                  float qx, float qy, SH& sh, int& ni, double& gbest, double& gsecond) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE_F);
+  const int per = roundup_i((n + SH::kNW - 1) / SH::kNW, WAVE_STRIDE_F);
   const int ws = w * per;
   const int we = ws + per;
   float best = __builtin_inff(), second = __builtin_inff();
@@ -334,7 +334,7 @@ template <class SH>
 __device__ __forceinline__ int scan_hits_f32(const float* __restrict__ xf, const float* __restrict__ yf, int n, float qx,
                                              float qy, float thr, int32_t* __restrict__ hits, SH& sh) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int per = roundup_i((n + NW - 1) / NW, WAVE_STRIDE_F);
+  const int per = roundup_i((n + SH::kNW - 1) / SH::kNW, WAVE_STRIDE_F);
   const int ws = w * per;
   const int we = ws + per;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -380,7 +380,7 @@ __device__ __forceinline__ int scan_hits_f32(const float* __restrict__ xf, const
   __syncthreads();
   int total = 0;
 #pragma unroll
-  for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
+  for (int k = 0; k < SH::kNW; k++) total += sh.wave_cnt[k];
   return total;
 }
 
@@ -459,7 +459,7 @@ template <class SH>
 __device__ __forceinline__ int hit_at(const int32_t* hits, const SH& sh, int h) {
   int k = 0;
 #pragma unroll
-  for (int j = 0; j < NW - 1; j++) {
+  for (int j = 0; j < SH::kNW - 1; j++) {
     if (k == j && h >= sh.wave_cnt[j]) {
       h -= sh.wave_cnt[j];
       k = j + 1;
@@ -472,7 +472,7 @@ template <class SH>
 __device__ __forceinline__ int hit_loc(const SH& sh, int h) {
   int k = 0;
 #pragma unroll
-  for (int j = 0; j < NW - 1; j++) {
+  for (int j = 0; j < SH::kNW - 1; j++) {
     if (k == j && h >= sh.wave_cnt[j]) {
       h -= sh.wave_cnt[j];
       k = j + 1;
@@ -498,7 +498,7 @@ __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const 
     sh.nvalid = 0;
   }
   __syncthreads();
-  for (int base = 0; base < kraw; base += TPB) {
+  for (int base = 0; base < kraw; base += SH::kTPB) {
     const int h = base + tid;
     int idx = -1;
     double v = 0.0;
@@ -520,7 +520,7 @@ __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const 
     sh.cval[tid] = cand ? v : rpp::b2d(0x7ff8000000000000ULL);   // NaN: never equal
     sh.cflag[tid] = cand ? 1 : 0;
     __syncthreads();
-    const int nchunk = (kraw - base) < TPB ? (kraw - base) : TPB;
+    const int nchunk = (kraw - base) < SH::kTPB ? (kraw - base) : SH::kTPB;
     bool earlier = false;
 #pragma unroll 4
     for (int t = 0; t < nchunk; t++) earlier |= (t < tid) & (sh.cval[t] == v);
@@ -534,11 +534,11 @@ __device__ __forceinline__ void exact_dedup(const double* __restrict__ x, const 
     __syncthreads();
     int off = nu;
 #pragma unroll
-    for (int k = 0; k < NW; k++)
+    for (int k = 0; k < SH::kNW; k++)
       if (k < w) off += sh.red_idx[k];
     int tot = nu;
 #pragma unroll
-    for (int k = 0; k < NW; k++) tot += sh.red_idx[k];
+    for (int k = 0; k < SH::kNW; k++) tot += sh.red_idx[k];
     if (first) {
       const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       int p = off + __popcll(mf & lt_mask);

@@ -69,6 +69,7 @@ struct rrtx_handle {
   std::vector<PoolLoc> pool_loc;
   int32_t* pool_slot = nullptr;  // device copy of the slab numbers of a re-plan
   int64_t stats_retried = 0;
+  int informed_eager = 0;        // rrt_07 kernel: 1 = collision-test every near candidate (reference order), 0 = cheapest first
   int v2_chunk_iters = 16384;   // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
   std::vector<rppi::InformedArgs> iargs;   // informed RRT*: per-instance rotation C / c_min**2 (centre filled at plan time)
@@ -604,6 +605,7 @@ int rrtx_plan(rrtx_handle* h) {
     h->da.pool_slot = nullptr;
   }
   if (const char* e = getenv("RRTX_RS_EAGER")) h->da.eager = atoi(e) != 0;
+  if (const char* e = getenv("RRTX_INFORMED_EAGER")) h->informed_eager = atoi(e) != 0;   // rrt_07: test every near candidate like the reference
   h->da.lazy = 0;
   h->da.filter = 1;
   if (const char* e = getenv("RRTX_DUBINS_FILTER")) h->da.filter = atoi(e) != 0;
@@ -620,7 +622,7 @@ int rrtx_plan(rrtx_handle* h) {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (c.algo == RRTX_ALGO_INFORMED)
       hipLaunchKernelGGL((rppi::rrt_informed_kernel<rppi::NUI_SMALL, 4>), dim3(B), dim3(rppi::TPB), 0, h->stream, c,
-                         h->d_iargs, h->cbest, h->chunk_iters);
+                         h->d_iargs, h->cbest, h->chunk_iters, h->informed_eager);
     else if (is_dubins(c.algo))
       hipLaunchKernelGGL(rppd::rrt_dubins_kernel, dim3(B), dim3(rppd::TPB), 0, h->stream, c, h->da, h->chunk_iters);
     else if (c.algo == RRTX_ALGO_RS)
@@ -821,7 +823,7 @@ int rrtx_plan(rrtx_handle* h) {
       for (int64_t guard = 0;; guard++) {
         HIPCHK(h, hipEventRecord(h->ev0, h->stream));
         hipLaunchKernelGGL((rppi::rrt_informed_kernel<rppi::NUI_LARGE, 1>), dim3(nr), dim3(rppi::TPB), 0, h->stream, cr,
-                           h->d_iargs, h->cbest, h->chunk_iters);
+                           h->d_iargs, h->cbest, h->chunk_iters, h->informed_eager);
         HIPCHK(h, hipGetLastError());
         HIPCHK(h, hipEventRecord(h->ev1, h->stream));
         HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));

@@ -27,8 +27,8 @@ ph = h.get_phase_cycles()
 names = {0: "sample", 1: "nearest scan", 2: "ext edge (cooperative)", 3: "choose: costs + ranking", 4: "near scan", 5: "exact+dedup",
          6: "choose: lane edges + argmin", 7: "winner edge + append", 8: "rewire: lane edges", 9: "rewire: sequential",
          15: "loop", 10: "  (candidates: prepare, both stages)", 11: "  (candidates: prefix sum)",
-         12: "  (candidates: points)"}
-tot = float(ph.sum() - ph[10] - ph[11] - ph[12])
+         12: "  (candidates: points)", 13: "  (ext edge: solver on 8 lanes)", 14: "  (ext edge: points + collision)"}
+tot = float(ph.sum() - ph[10] - ph[11] - ph[12] - ph[13] - ph[14])
 print("instances", B, "max_iter", it, "kernel_ms", s["kernel_ms"])
 for k in sorted(names):
     print("  %-30s %6.2f%%  %.1f cycles/iter/inst" % (names[k], 100.0 * ph[k] / tot if tot else 0, ph[k] / max(s["iterations"], 1)))
