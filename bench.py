@@ -560,10 +560,26 @@ def main():
                 line[k + "_last_step"] = ls[k]
         if a.workload in ("c5", "c6"):
             line["edges_steered_per_iteration"] = tot_eu / max(tot_it, 1)
+            # what the reference steers for the same trees: the extension plus every near-list entry twice (choose_parent,
+            # rewire); from this rank's counters of the last step (the kernels count only what the device steers)
+            if ls.get("iterations") and tmax > 0:
+                per_it = 1.0 + 2.0 * ls.get("near_hits", 0) / ls["iterations"]
+                line["edge_expansions_reference_equivalent_per_s"] = per_it * tot_it / tmax
+                line["reference_edges_per_iteration_estimate"] = per_it
             line["value_note"] = ("`value` counts the edges the device steers.  The default build steers only the "
                                   "candidates that can change the result (DESIGN.md 5.5 / 5.7: same trees, several times "
-                                  "fewer edges); the reference and the CPU baseline steer every near candidate -- compare "
-                                  "plans_per_s / iterations_per_s with the CPU baseline, not the edge rates")
+                                  "fewer edges); the reference and the CPU baseline steer every near candidate: "
+                                  "edge_expansions_reference_equivalent_per_s = (1 + 2 x near-list entries per iteration) x "
+                                  "iterations/s, an upper estimate (an entry whose steer returns None is not collision-"
+                                  "checked by the reference; rrt_06's try_goal_path edge is not counted) -- compare "
+                                  "plans_per_s / iterations_per_s with the CPU baseline, not the device's edge rate")
+        if a.workload == "c3":
+            line["edges_tested_per_iteration"] = tot_eu / max(tot_it, 1)
+            line["value_note"] = ("`value` counts the segments the device collision-tests: choose_parent tests the near "
+                                  "candidates cheapest first and stops at the first free one, rewire tests only candidates "
+                                  "whose cost improves (DESIGN.md 5.8: same trees; RRTX_INFORMED_EAGER=1 tests every candidate); "
+                                  "edge_expansions_reference_equivalent_per_s counts check_collision calls as the reference "
+                                  "makes them for the same trees")
         if c4:
             line["unit"] = "edge expansions/s"
             roof["note"] += "; BIT* is an instance-parallel sequential search (one wave per instance, state in LDS)"

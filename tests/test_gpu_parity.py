@@ -321,6 +321,43 @@ def test_gpu_informed_batch_equals_oracle(gpu):
             assert np.array_equal(out["paths"][i], r["path"]) and out["results"][0][i] == r["c_best"]
 
 
+def test_gpu_informed_candidate_order_does_not_change_the_tree(gpu, monkeypatch):
+    """rrt_07 kernel: the default candidate order (choose_parent cheapest first in growing batches, rewire tests only
+    candidates whose cost improves) against RRTX_INFORMED_EAGER=1 (every near candidate tested, as the reference does) and
+    against the oracle -- C3-style scene, and a cluttered scene where most cheapest candidates are blocked (the batches grow)."""
+    import oracle
+    g = util.load_golden(util.GOLDEN + "/rrt07_c3_sobol_s1_it3000.npz")
+    kw = util.informed_kwargs_from_golden(g)
+    kw["max_iter"] = 2500
+    import random as _r
+    rr = _r.Random(5)
+    dense = dict(kw)
+    dense["obstacles"] = []
+    while len(dense["obstacles"]) < 200:     # 200 circles on a quarter of the C3 map: ~20 % of the area is blocked
+        ox, oy, orad = rr.uniform(0, 50), rr.uniform(0, 50), rr.uniform(0.3, 1.5)
+        if min((ox - 2) ** 2 + (oy - 2) ** 2, (ox - 48) ** 2 + (oy - 48) ** 2) > (orad + 3) ** 2:
+            dense["obstacles"].append((ox, oy, orad))
+    dense.update(start=[2.0, 2.0], goal=[48.0, 48.0], rand_area=[0.0, 50.0], expand_dis=1.5, max_iter=2500)
+    for name, k in (("c3", kw), ("dense", dense)):
+        seeds = list(range(1, 9))
+        lazy = util.run_gpu_informed(k, seeds)
+        monkeypatch.setenv("RRTX_INFORMED_EAGER", "1")
+        eager = util.run_gpu_informed(k, seeds)
+        monkeypatch.delenv("RRTX_INFORMED_EAGER")
+        for i, s in enumerate(seeds):
+            r = oracle.plan_informed(seed=s, **k)
+            ref = (r["x"], r["y"], r["cost"], r["parent"])
+            util.assert_tree_equal(lazy["trees"][i], ref, "%s default order, seed %d" % (name, s))
+            util.assert_tree_equal(eager["trees"][i], ref, "%s eager, seed %d" % (name, s))
+            assert (lazy["paths"][i] is None) == (r["path"] is None)
+            if r["path"] is not None:
+                assert np.array_equal(lazy["paths"][i], r["path"]) and lazy["results"][0][i] == r["c_best"]
+        # the reference-equivalent count is the same, the device tests several times fewer segments
+        assert lazy["stats"]["edges_ref"] == eager["stats"]["edges_ref"]
+        assert lazy["stats"]["edges_unique"] * 2 < eager["stats"]["edges_unique"]
+        assert lazy["stats"]["rewires"] == eager["stats"]["rewires"]
+
+
 def test_informed_host_class_drop_in(gpu):
     import random
     import rrt_amd

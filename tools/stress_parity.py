@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stress parity (GPU box): many seeds per planner, GPU trees vs the golden-pinned oracle, bit for bit.
-Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 / STRESS_ONLY=moved run that block only)"""
+Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 / STRESS_ONLY=moved run that block only,
+STRESS_ONLY=pose the rrt_05 / rrt_03 / rrt_07 blocks)"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -101,7 +102,8 @@ if __name__ == "__main__":
                     ("curvature 1, step 0.2, radius 0, goal yaw 1.2, 1000 it",
                      {"curvature": 1.0, "step_size": 0.2, "robot_radius": 0.0, "max_iter": 1000,
                       "goal": np.array([10.0, 9.0, 1.2])}))
-        for nm, upd in (() if os.environ.get("STRESS_ONLY") == "moved" else rs_cases):
+        POSE = os.environ.get("STRESS_ONLY") == "pose"
+        for nm, upd in (() if os.environ.get("STRESS_ONLY") in ("moved", "pose") else rs_cases):
             g = dict(G06); g.update(upd)
             out = util.run_gpu_rrt_rs(g, seeds)
             total += compare("rrt_06 " + nm, out["trees"], list(ex.map(o06, [(s, g) for s in seeds])))
@@ -110,7 +112,7 @@ if __name__ == "__main__":
             sys.exit(1 if total else 0)
         # rrt_04 with inexact path resolutions: rewires that MOVE their node (rrt_04:1372), many of them in iterations
         # whose near_inds repeats indices (goal duplicates) -> raw-list walk of the general kernel (`replanned`)
-        for res, rate, it in ((0.05, 95, 400), (0.05, 20, 400), (0.1, 60, 400), (0.3, 95, 600)):
+        for res, rate, it in (() if POSE else ((0.05, 95, 400), (0.05, 20, 400), (0.1, 60, 400), (0.3, 95, 600))):
             kwm = dict(util.C2)
             kwm.update(start=[0, 0], goal=[6, 8], rand_area=[-2, 12], obstacles=[(3, 3, 1)], expand_dis=3.0,
                        path_resolution=res, goal_sample_rate=rate, connect_circle_dist=50.0, max_iter=it, robot_radius=0.0)
@@ -132,19 +134,35 @@ if __name__ == "__main__":
             total += compare("rrt_03 driver, 3000 it, sobol=%d" % sob, out["trees"],
                              list(ex.map(o03, [(s, 3000, sob) for s in seeds])))
         # rrt_04: C2 map and driver map (play area, robot radius), MT and Sobol
-        for sob in (0, 1):
+        for sob in (() if POSE else (0, 1)):
             kw = util.c2_kwargs(4000); kw["sobol"] = sob
             out = util.run_gpu_batch(kw, seeds)
             total += compare("rrt_04 C2 map, 4000 it, sobol=%d" % sob, out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
-        kw = util.kwargs_from_golden(util.load_golden(util.GOLDEN + "/rrt04_drv_mt_s1234.npz")); kw["max_iter"] = 2000
-        out = util.run_gpu_batch(kw, seeds)
-        total += compare("rrt_04 driver map, 2000 it", out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
+        if not POSE:
+            kw = util.kwargs_from_golden(util.load_golden(util.GOLDEN + "/rrt04_drv_mt_s1234.npz")); kw["max_iter"] = 2000
+            out = util.run_gpu_batch(kw, seeds)
+            total += compare("rrt_04 driver map, 2000 it", out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
         # rrt_07
         for gg, it, nm in ((G07, 3000, "C3-style map"), (G07D, 2000, "driver map")):
             kw7 = util.informed_kwargs_from_golden(gg)
             kw7["max_iter"] = it
             out = util.run_gpu_informed(kw7, seeds)
             total += compare("rrt_07 %s, %d it" % (nm, it), out["trees"], list(ex.map(o07, [(s, kw7) for s in seeds])))
+        # rrt_07, cluttered quarter map: most of the cheapest choose_parent candidates are blocked (the device's batches grow)
+        import random as _r
+        rr = _r.Random(5)
+        kwd7 = util.informed_kwargs_from_golden(G07)
+        kwd7["obstacles"] = []
+        while len(kwd7["obstacles"]) < 200:
+            ox, oy, orad = rr.uniform(0, 50), rr.uniform(0, 50), rr.uniform(0.3, 1.5)
+            if min((ox - 2) ** 2 + (oy - 2) ** 2, (ox - 48) ** 2 + (oy - 48) ** 2) > (orad + 3) ** 2:
+                kwd7["obstacles"].append((ox, oy, orad))
+        kwd7.update(start=[2.0, 2.0], goal=[48.0, 48.0], rand_area=[0.0, 50.0], expand_dis=1.5, max_iter=2500)
+        out = util.run_gpu_informed(kwd7, seeds)
+        total += compare("rrt_07 cluttered quarter map, 2500 it", out["trees"], list(ex.map(o07, [(s, kwd7) for s in seeds])))
+        if POSE:
+            print("TOTAL mismatches", total)
+            sys.exit(1 if total else 0)
         # rrt_01 (plain RRT, early exit) and rrt_04 early-exit mode on the driver map
         kw1 = util.kwargs_from_golden(util.load_golden(sorted(util.golden_files("rrt01_drv"))[0]))
         out = util.run_gpu_batch(kw1, seeds)
