@@ -5,7 +5,8 @@
 #   1. rocprofv3 passes of the headline bench: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)
 #      -> profiles/r2_c2_kernel_stats.csv, r2_c2_pmc_*.csv, r2_c2_traffic.json (device-code hash + commit inside)
 #   2. the driver's exact bench command under its 600 s limit -> r2_bench_c2_driver_cmd.json (reads the traffic file of 1.)
-#   3. per-phase split of the C2 iteration (diagnostic build) -> r2_c2_phase_4096x105k.txt
+#   3. per-phase split of the C2 iteration (diagnostic build) -> r2_c2_phase_4096x105k.txt; the same for the rrt_07 / rrt_05 kernels
+#      (needs robotics-path-planning_amd/librrtx_prof.so: `make -C robotics-path-planning_amd/csrc prof`, and tools/ubench/lat_ubench)
 #   4. C3..C6: bench line + VALU PMC pass -> r2_bench_<w>.json, r2_<w>_valu.json
 # Everything is written under gpurun_out/r2/ (merged back by gpurun); copy it into profiles/ and commit.
 export RRTX_COMMIT=${RRTX_COMMIT:-unknown}
@@ -20,6 +21,9 @@ timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r2_bench_
 echo "driver bench rc=$?"
 RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile.py 4096 105000 > $O/r2_c2_phase_4096x105k.txt 2>&1
 echo "phase rc=$?"
+RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c3.py 1024 20000 > $O/r2_c3_phase.txt 2>&1
+RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c5.py 1536 5000 > $O/r2_c5_phase.txt 2>&1
+echo "phase c3/c5 rc=$?"
 for w in c3 c4 c5 c6; do
   bash tools/valu_pass.sh $w > $O/valu_$w.log 2>&1
   cp gpurun_out/r2_${w}_valu.json $O/ 2>/dev/null
