@@ -58,7 +58,7 @@ struct rrtx_handle {
   int64_t phase[16] = {0};
   std::string err;
   std::vector<void*> allocs;
-  int chunk_iters = 8192;        // iterations per launch of the other planner kernels
+  int chunk_iters = 32768;       // iterations per launch of the other planner kernels
   int32_t* inst_map = nullptr;   // device: instance ids of a partial re-plan (overflow retry)
   // pose planners: where an instance's edge polylines live -- the handle's pool (slab = instance), or a larger pool
   // allocated for instances that outgrew it (slab = position in that re-plan)
@@ -70,7 +70,7 @@ struct rrtx_handle {
   int32_t* pool_slot = nullptr;  // device copy of the slab numbers of a re-plan
   int64_t stats_retried = 0;
   int informed_eager = 0;        // rrt_07 kernel: 1 = collision-test every near candidate (reference order), 0 = cheapest first
-  int v2_chunk_iters = 16384;   // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
+  int v2_chunk_iters = 131072;  // iterations per launch of the RRT* iteration kernel (rrt_star_v2_body.inc)
   double* cbest = nullptr;  // informed RRT*: best path length so far per instance (device)
   std::vector<rppi::InformedArgs> iargs;   // informed RRT*: per-instance rotation C / c_min**2 (centre filled at plan time)
   std::vector<double> icmin;               // informed RRT*: per-instance c_min as handed in
@@ -207,10 +207,11 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
   memset(&h->stats, 0, sizeof(h->stats));
   memset(&h->c, 0, sizeof(h->c));
   // Iterations per kernel launch.  A launch ends when its slowest instance does, so short chunks leave the chip
-  // part idle at the end of every launch: 1024-iteration chunks cost the C2 batch 9 % (103 launches) against one launch;
-  // 16384 (8192 for the other kernels) keeps that under 2 % and still returns to the host every few seconds.
+  // part idle at the end of every launch: 1024-iteration chunks cost the C2 batch 9 % (103 launches) against one launch,
+  // 16384-iteration chunks (7 launches) still 1.9 % (18.47 vs 18.12 s, same box).  A plan of up to 131072 iterations
+  // (32768 for the other kernels) is ONE launch now -- C2's 105000 iterations: 18 s of kernel time.
   if (const char* e = getenv("RRTX_CHUNK_ITERS")) {
-    h->chunk_iters = atoi(e) > 0 ? atoi(e) : 8192;
+    h->chunk_iters = atoi(e) > 0 ? atoi(e) : 32768;
     h->v2_chunk_iters = h->chunk_iters;
   }
   *out = h;  // returned even on failure below so the caller can read last_error, then destroy

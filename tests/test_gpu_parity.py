@@ -358,6 +358,40 @@ def test_gpu_informed_candidate_order_does_not_change_the_tree(gpu, monkeypatch)
         assert lazy["stats"]["rewires"] == eager["stats"]["rewires"]
 
 
+def test_gpu_plans_resume_across_kernel_launches(gpu, monkeypatch):
+    """A plan is one kernel launch by default (131 072 / 32 768 iterations per launch); longer plans, and RRTX_CHUNK_ITERS, split
+    it, and every launch resumes from the state the previous one stored (tree, RNG / Sobol state, prefetched nearest query,
+    c_best, polyline pool).  300-iteration launches against the reference goldens, one planner per kernel."""
+    monkeypatch.setenv("RRTX_CHUNK_ITERS", "300")
+    g = util.load_golden(util.GOLDEN + "/rrt04_c2_s1_it4000.npz")                     # rrt_04 iteration kernel
+    out = util.run_gpu_batch(util.kwargs_from_golden(g), [int(g["seed"])])
+    _check_against_golden(g, out)
+    g = util.load_golden(util.GOLDEN + "/rrt04_c2_sobol_s4_it1500.npz")
+    out = util.run_gpu_batch(util.kwargs_from_golden(g), [int(g["seed"])])
+    _check_against_golden(g, out)
+    assert out["sobol_index"][0] == int(g["sobol_index_after"])
+    g = util.load_golden(util.GOLDEN + "/rrt01_drv_s42.npz")                          # general kernel
+    _check_against_golden(g, util.run_gpu_batch(util.kwargs_from_golden(g), [int(g["seed"])]))
+    g = util.load_golden(util.GOLDEN + "/rrt07_c3_sobol_s1_it3000.npz")               # rrt_07
+    out = util.run_gpu_informed(util.informed_kwargs_from_golden(g), [int(g["seed"])])
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert (out["paths"][0] is None) == (len(g["path"]) == 0)
+    if len(g["path"]):
+        assert np.array_equal(out["paths"][0], g["path"]) and out["results"][0][0] == float(g["path_len"])
+    g = util.load_golden(util.GOLDEN + "/rrt05_drv_s3_it1500.npz")                    # rrt_05
+    out = util.run_gpu_dubins(g, [int(g["seed"])])
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    assert np.array_equal(out["yaws"][0], g["yaw"]) and np.array_equal(out["polys"][0][1], g["poly_x"])
+    g = util.load_golden(util.GOLDEN + "/rrt03_drv_s9_it1500_mt.npz")                 # rrt_03 (same kernel, plain mode)
+    out = util.run_gpu_rrt_dubins(g, [int(g["seed"])])
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    g = util.load_golden(util.GOLDEN + "/rrt06_drv_s7_it750.npz")                     # rrt_06
+    out = util.run_gpu_rrt_rs(g, [int(g["seed"])])
+    util.assert_tree_equal(out["trees"][0], (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    if len(g["path"]):
+        assert np.array_equal(out["paths"][0], g["path"][:, :2]) and np.array_equal(out["path_yaws"][0], g["path"][:, 2])
+
+
 def test_informed_host_class_drop_in(gpu):
     import random
     import rrt_amd
