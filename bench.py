@@ -428,6 +428,11 @@ def main():
         import torch.distributed as dist
         if a.dry_run:
             dist.init_process_group(backend="gloo")
+        elif os.environ.get("RRTX_BENCH_SHARE_GPU"):
+            # rehearsal of the N-rank path on a box with ONE GPU (RCCL refuses two ranks on one device): every rank plans on
+            # device 0, the collectives run over gloo on host tensors.  The line carries "rehearsal": true; never a headline
+            dist.init_process_group(backend="gloo")
+            local_rank = 0
         else:
             torch.cuda.set_device(local_rank)
             cuda = torch.device("cuda", local_rank)
@@ -597,6 +602,8 @@ def main():
             roof["note"] += "; BIT* is an instance-parallel sequential search (one wave per instance, state in LDS)"
         if cpu is not None:
             line["cpu_baseline"] = cpu
+        if os.environ.get("RRTX_BENCH_SHARE_GPU"):
+            line["rehearsal"] = "all ranks share GPU 0, gloo collectives: exercises the launch / sharding / report path only"
         if a.dry_run:
             line["dry_run"] = True
             line["value"] = None

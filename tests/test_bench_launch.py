@@ -80,3 +80,27 @@ def test_result_records_round_trip():
     # a record without ST_PATH reads back as +inf whatever the stored cost
     pc3, _, _ = sharding.unpack_records(sharding.pack_records(np.array([5.0]), np.array([1]), np.array([1])))
     assert np.isinf(pc3[0])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_shards_on_one_gpu_equal_the_single_shard_run():
+    """SURVEY 8(e), "test without 8 GPUs": two rank processes (self-launched by bench.py) plan their shards on the ONE GPU
+    of the box and gather their result tables (RRTX_BENCH_SHARE_GPU=1: gloo collectives -- RCCL refuses two ranks on one
+    device); the gathered table must be the single-shard run's: same instances found, same mean cost and tree size to the
+    last bit (rank r owns seeds r*B+1 ... (r+1)*B, the single run seeds 1 ... 2B)."""
+    common = ["--steps", "1", "--warmup", "0", "--max-iter", "2000", "--no-cpu-baseline"]
+    r2 = _run(["--gpus", "2", "--instances", "48"] + common, env_extra={"RRTX_BENCH_SHARE_GPU": "1"})
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    r1 = _run(["--gpus", "1", "--instances", "96"] + common)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    l2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+    l1 = [ln for ln in r1.stdout.splitlines() if ln.startswith("{")]
+    assert len(l2) == 1 and len(l1) == 1
+    j2, j1 = json.loads(l2[0]), json.loads(l1[0])
+    assert j2["n_gpus"] == 2 and j2["instances_total"] == 96 and j1["instances_total"] == 96 and "rehearsal" in j2
+    for k in ("paths_found", "final_path_cost_mean", "final_path_cost_min", "mean_nodes_per_tree"):
+        assert j2[k] == j1[k], k
+    assert j2["iterations_per_s"] > 0 and j2["roofline"]["frac"] > 0
