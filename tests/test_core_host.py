@@ -11,6 +11,9 @@ import pytest
 import util
 
 CSRC = os.path.join(util.ROOT, "robotics-path-planning_amd", "csrc")
+# RRTX_TEST_SANITIZE=1: build the host checks with AddressSanitizer + UndefinedBehaviorSanitizer (run pytest with
+# LD_PRELOAD=$(gcc -print-file-name=libasan.so) so that the shared-object check loads too); CPU only
+SAN = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("RRTX_TEST_SANITIZE") else []
 
 
 @pytest.fixture(scope="module")
@@ -22,7 +25,7 @@ def test_core_against_oracle(builddir):
     import oracle
     oracle.lib()
     exe = os.path.join(builddir, "core_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-I", CSRC,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma"] + SAN + ["-I", CSRC,
                     os.path.join(util.ROOT, "tests", "native", "core_host_check.cpp"), "-o", exe, "-ldl"], check=True)
     r = subprocess.run([exe, os.path.join(util.ROOT, "oracle", "liboracle.so"), "200000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -31,7 +34,7 @@ def test_core_against_oracle(builddir):
 def test_glibc_replicas_against_live_libm(builddir):
     src = os.path.join(util.ROOT, "tests", "native", "glibc_replica_check.c")
     exe = os.path.join(builddir, "glibc_check")
-    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-fno-builtin", "-I", CSRC, src, "-o", exe, "-lm"],
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-fno-builtin"] + SAN + ["-I", CSRC, src, "-o", exe, "-lm"],
                    check=True)
     r = subprocess.run([exe, "5000000"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -115,7 +118,7 @@ def test_bitstar_core_against_goldens_and_oracle(builddir):
     import ctypes as C
     import oracle
     so = os.path.join(builddir, "libbitstar_host.so")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-mfma", "-I", CSRC,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-mfma"] + SAN + ["-I", CSRC,
                     os.path.join(util.ROOT, "tests", "native", "bitstar_host.cpp"), "-o", so], check=True)
     L = C.CDLL(so)
 
@@ -177,7 +180,7 @@ def test_reeds_shepp_core_against_reference_kat(builddir):
                     f.write(np.asarray(g[key][off:off + n], dtype=np.float64).tobytes())
                 off += n
     exe = os.path.join(builddir, "rs_check")
-    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma", "-I", CSRC,
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-mfma"] + SAN + ["-I", CSRC,
                     os.path.join(util.ROOT, "tests", "native", "rs_host_check.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe, blob], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
