@@ -258,8 +258,10 @@ class RRTSobol(RRT):
     """Drop-in for rrt_02's `RRT` (10_path_planning_01_rrt_02_sobol_sampler.py:932-1089): rrt_01 whose
     get_random_node draws the 2-D Sobol sequence (:1077-1089)."""
 
-    def __init__(self, *args, **kwargs):
-        super().__init__(*args, **kwargs)
+    def __init__(self, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
+                 goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, device=0):
+        super().__init__(start, goal, obstacle_list, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
+                         play_area, robot_radius, device)
         self.sobol_inter_ = 0
 
     def planning(self, animation=True):

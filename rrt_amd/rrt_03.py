@@ -1,0 +1,8 @@
+"""Names of /root/reference/src_path_planning/10_path_planning_01_rrt_03_dubins_path.py as its driver cell uses them: RRT :1349-1700 (RRT with Dubins steer).
+Each is the MI355X mirror class / function of robotics-path-planning_amd/planner.py (same constructor keywords and
+defaults, same entry points and return shapes)."""
+from . import planner as _p
+
+RRT = _p.RRTDubins
+
+__all__ = ['RRT']
