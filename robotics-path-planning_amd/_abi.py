@@ -25,7 +25,7 @@ EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obs
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_copy_results_device", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_trace_kind", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
-           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw"]
+           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw", "rrtx_selfcheck"]
 
 
 class Params(C.Structure):
@@ -102,6 +102,7 @@ def load():
     L.rrtx_smooth_planned.argtypes = [vp, i32]
     L.rrtx_get_smoothed_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.rrtx_get_path_yaw.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
+    L.rrtx_selfcheck.argtypes = [i32, i32, vp]
     for f in EXPORTS:
         if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
             getattr(L, f).restype = C.c_int
@@ -109,6 +110,49 @@ def load():
         raise RrtxError("librrtx.so ABI version mismatch")
     _lib = L
     return L
+
+
+class RrtxParityWarning(UserWarning):
+    """The host's arithmetic (libm / CPython math) is not the one the device replicas restate: results are
+    self-consistent but match a reference run ON THIS HOST only up to libm's few-ULP differences."""
+
+
+_selfchecked = {}
+SELFCHECK_FUNCS = ("pow(x,2)", "sin", "cos", "atan2", "acos", "asin", "sqrt", "a/b", "math.hypot", "float**2")
+
+
+def selfcheck(device=0, n=4096, warn=True):
+    """Run-time check of the arithmetic contract, once per process and device: the device's libm
+    replicas against the host's libm (rrtx_selfcheck, native), and the two CPython-specific forms -- math.hypot
+    (CPython 3.10's own algorithm) and float ** 2 -- against THIS interpreter.  Returns {function: mismatches}; with
+    `warn`, emits RrtxParityWarning when any is non-zero.  RRTX_SELFCHECK=0 skips the automatic call made by the first
+    Handle of a process."""
+    import math
+    import warnings
+    if device in _selfchecked:
+        return _selfchecked[device]
+    L = load()
+    mm = np.zeros(8, dtype=np.int64)
+    rc = L.rrtx_selfcheck(int(device), int(n), mm.ctypes.data)
+    if rc != 0:
+        raise RrtxError("rrtx_selfcheck: %s" % ERRORS.get(rc, rc))
+    rng = np.random.RandomState(20240607)
+    a = rng.uniform(-300.0, 300.0, n)
+    b = rng.uniform(-300.0, 300.0, n)
+    a[::5] /= 4096.0
+    hyp = selftest_math(0, a, b, device)
+    sq = selftest_math(1, a, b, device)
+    res = {SELFCHECK_FUNCS[k]: int(mm[k]) for k in range(8)}
+    res["math.hypot"] = int(sum(1 for i in range(n) if math.hypot(float(a[i]), float(b[i])) != float(hyp[i])))
+    res["float**2"] = int(sum(1 for i in range(n) if float(a[i]) ** 2 != float(sq[i])))
+    _selfchecked[device] = res
+    bad = {k: v for k, v in res.items() if v}
+    if bad and warn:
+        warnings.warn("librrtx: device arithmetic differs from this host's on %s of %d arguments each: results are "
+                      "identical to the reference only on glibc 2.35 (x86-64 FMA variants) + CPython 3.10; here they "
+                      "agree to libm's few-ULP differences and integer results can differ at near-ties"
+                      % (bad, n), RrtxParityWarning, stacklevel=2)
+    return res
 
 
 class Handle:
@@ -154,6 +198,8 @@ class Handle:
                 self.L.rrtx_destroy(self._h)
                 self._h = C.c_void_p()
             raise RrtxError("rrtx_create: %s %s" % (ERRORS.get(rc, rc), msg))
+        if os.environ.get("RRTX_SELFCHECK", "1") != "0" and int(device) not in _selfchecked:
+            selfcheck(int(device))   # once per process and device: warns when this host's libm is not the replicated one
 
     def _chk(self, rc, what):
         if rc < 0:

@@ -33,6 +33,11 @@ namespace {
 double (*volatile libm_pow)(double, double) = pow;
 double (*volatile libm_log)(double) = log;
 double (*volatile libm_sqrt)(double) = sqrt;
+double (*volatile libm_sin)(double) = sin;
+double (*volatile libm_cos)(double) = cos;
+double (*volatile libm_atan2)(double, double) = atan2;
+double (*volatile libm_acos)(double) = acos;
+double (*volatile libm_asin)(double) = asin;
 
 inline double py_sq_host(double x) {
   if (x == 0.0) return 0.0;
@@ -1347,6 +1352,52 @@ int rrtx_selftest_math(int32_t device, int32_t op, const double* a, const double
   hipFree(db);
   hipFree(dout);
   return rc;
+}
+
+int rrtx_selfcheck(int32_t device, int32_t n_per_fn, int64_t* mismatches8) {
+  if (!mismatches8 || n_per_fn < 1 || n_per_fn > (1 << 22)) return RRTX_E_INVALID;
+  const int64_t n = n_per_fn;
+  std::vector<double> a(n), b(n), out(n);
+  // splitmix64 -> uniform in [0, 1): the same arguments on every host
+  uint64_t sm = 0x9e3779b97f4a7c15ULL;
+  auto u01 = [&]() {
+    uint64_t z = (sm += 0x9e3779b97f4a7c15ULL);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+  };
+  // selftest op, argument ranges: coordinates differences up to a few hundred, angles within a few turns (Dubins /
+  // Reeds-Shepp sums, 2*pi*a/b of the unit-ball sample), |x| <= 1 for the inverse functions
+  struct Fn { int op; double lo_a, hi_a, lo_b, hi_b; } fns[8] = {
+      {1, -300.0, 300.0, 0.0, 1.0}, {2, -20.0, 20.0, 0.0, 1.0}, {3, -20.0, 20.0, 0.0, 1.0}, {4, -300.0, 300.0, -300.0, 300.0},
+      {8, -1.0, 1.0, 0.0, 1.0},     {9, -1.0, 1.0, 0.0, 1.0},   {6, 0.0, 1.0e5, 0.0, 1.0},  {7, -300.0, 300.0, -300.0, 300.0}};
+  for (int f = 0; f < 8; f++) {
+    for (int64_t i = 0; i < n; i++) {
+      a[i] = fns[f].lo_a + (fns[f].hi_a - fns[f].lo_a) * u01();
+      b[i] = fns[f].lo_b + (fns[f].hi_b - fns[f].lo_b) * u01();
+      if (i % 7 == 3 && (fns[f].op == 1 || fns[f].op == 4)) a[i] *= 1.0 / 1024.0;   // small arguments too
+    }
+    int rc = rrtx_selftest_math(device, fns[f].op, a.data(), b.data(), out.data(), n);
+    if (rc) return rc;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n; i++) {
+      double r;
+      switch (fns[f].op) {
+        case 1: r = py_sq_host(a[i]); break;
+        case 2: r = libm_sin(a[i]); break;
+        case 3: r = libm_cos(a[i]); break;
+        case 4: r = libm_atan2(a[i], b[i]); break;
+        case 8: r = libm_acos(a[i]); break;
+        case 9: r = libm_asin(a[i]); break;
+        case 6: r = libm_sqrt(a[i]); break;
+        default: r = a[i] / b[i]; break;
+      }
+      if (memcmp(&r, &out[i], 8) != 0) bad++;
+    }
+    mismatches8[f] = bad;
+  }
+  return RRTX_OK;
 }
 
 }  // extern "C"

@@ -90,6 +90,25 @@ def _check_against_golden(g, out, i=0):
     assert st[1][624] == int(g["rng_pos_after"]) and st[1][0] == int(g["rng_word0_after"])
 
 
+def test_runtime_selfcheck_of_the_arithmetic_contract(gpu):
+    """rrtx_selfcheck (native: device replicas vs the HOST's libm) + the Python side (math.hypot, float ** 2 vs this
+    interpreter): on the image the goldens come from every count is zero and no RrtxParityWarning is raised; the first
+    Handle of a process runs it by itself."""
+    import warnings
+    import rrt_amd
+    A = rrt_amd._abi
+    A._selfchecked.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", A.RrtxParityWarning)
+        res = A.selfcheck(0, n=20000)
+        assert set(res) == set(A.SELFCHECK_FUNCS) and all(v == 0 for v in res.values()), res
+        assert A.selfcheck(0) is res            # cached per device
+        A._selfchecked.clear()
+        h = A.Handle(A.ALGO_RRT, [0, 0], [6, 10], [-2, 15], 1.0, 0.1, 5, 10)   # the automatic call
+        h.close()
+        assert 0 in A._selfchecked and not any(A._selfchecked[0].values())
+
+
 @pytest.mark.parametrize("path", util.golden_files(), ids=lambda p: p.split("/")[-1][:-4])
 def test_gpu_matches_reference_golden(gpu, path):
     g = util.load_golden(path)

@@ -632,6 +632,15 @@ HEADER = r"""// GENERATED by tools/lift_libm.py -- do not edit.
 // pow / atan2 / sin / cos (the entry points CPython's math.* and float ** reach
 // on this image), so that device code takes the same roundings as the reference
 // planners' CPython arithmetic (rrt_04:1100-1101,1198,1236-1237 etc).
+// PROVENANCE AND LICENCE.  This file is machine-derived from the glibc BINARY installed in the build image
+// (/lib/x86_64-linux-gnu/libm.so.6, sha256 below; GNU C Library 2.35, Copyright (C) Free Software Foundation, Inc.,
+// licensed under the GNU Lesser General Public License v2.1 or later): tools/lift_libm.py walks the scalar-double
+// instruction stream of the x86-64 FMA ifunc variants of sin / cos / atan2 / pow / acos / asin (the entry points
+// CPython's math module reaches) and emits one C statement per instruction, and copies their lookup tables as data.  It is
+// therefore a translation of LGPL code and is distributed under the same terms (LGPL-2.1-or-later); it is NOT taken
+// from /root/reference, which contains no libm.  Regenerate with `python3 tools/lift_libm.py` on a host whose libm the
+// planners should reproduce.  The contract "doubles identical to the reference" holds on hosts whose libm returns
+// the same values (glibc 2.35 x86-64 with FMA); rrtx_selfcheck() / _abi.selfcheck() test that at run time.
 // libm sha256: %(sha)s
 #pragma once
 #include <stdint.h>
