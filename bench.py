@@ -48,6 +48,16 @@ def elapsed():
     return time.perf_counter() - T_PROCESS_START
 
 
+def profile_file(suffix):
+    """profiles/r<N>_<suffix> of the newest round that has one (the files carry the device-code hash they were measured
+    on; a file of other code is reported as such, never used)."""
+    for rnd in ("r3", "r2"):
+        f = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix))
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", "r3_%s" % suffix)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup-max-iter", type=int, default=3000,
                     help="iterations of a warm-up step (0 = same as a timed step); a warm-up only has to page in the "
                          "code objects and allocations, a full-size C2 pass takes tens of seconds")
-    ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("RRTX_BENCH_MAX_SECONDS", "240")),
+    ap.add_argument("--max-seconds", type=float, default=float(os.environ.get("RRTX_BENCH_MAX_SECONDS", "480")),
                     help="time budget from process start (setup, CPU baseline and warm-up included); the JSON reports "
                          "the steps actually timed")
     ap.add_argument("--dry-run", action="store_true",
@@ -284,6 +294,21 @@ def _cpu_job(args):
     return out + (time.perf_counter() - t,)
 
 
+def cgroup_cpu_quota():
+    """CPUs' worth of time the cgroup of this process may use (cpu.max of cgroup v2, cfs quota of v1), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -305,7 +330,12 @@ def cpu_baseline(wl, budget_s):
         ncore = len(os.sched_getaffinity(0))
     except AttributeError:
         ncore = os.cpu_count() or 1
-    nwork = max(1, min(ncore, 16))
+    # one instance per core over all cores.  "All cores" = what this process may really use: the
+    # affinity mask, cut by a cgroup CPU quota when the box sets one (a GPU box hands a 1-GPU job a share of its host),
+    # and by RRTX_BENCH_CPU_WORKERS (default 64: one forked worker per job, each a full oracle plan)
+    quota = cgroup_cpu_quota()
+    cap = int(os.environ.get("RRTX_BENCH_CPU_WORKERS", "64"))
+    nwork = max(1, min(ncore, cap, int(quota) if quota and quota >= 1 else ncore))
     # sample sizes aimed at ~budget/3 per leg on one core (measured rates of the oracle on a 2.1 GHz Xeon core)
     scale = max(0.25, min(4.0, budget_s / 12.0))
     per_job = 1
@@ -351,7 +381,7 @@ def cpu_baseline(wl, budget_s):
     plans = unit == "plans/s"
     out = {"value": (plN if plans else euN) / tB, "unit": unit, "cores": nwork, "kind": "port",
            "single_thread_value": (pl1 if plans else eu1) / tA,
-           "nproc": ncore, "cpu_model": cpu_model(),
+           "nproc": ncore, "cgroup_cpu_quota": quota, "cpu_model": cpu_model(),
            "sample": "oracle/rrt_oracle.c (C restatement pinned to the reference's goldens); same workload, %s; "
                      "single thread: %d plan(s) in %.1f s; all cores: one job per core on %d cores in %.1f s (of %d "
                      "visible cores); every near candidate steered as the reference does"
@@ -361,6 +391,16 @@ def cpu_baseline(wl, budget_s):
     if not plans:
         out["reference_equivalent_value"] = erN / tB
         out["plans_per_s"] = plN / tB
+    # the full-size single-thread rate (one whole plan at the workload's own max_iter: minutes of CPU time, so it is
+    # measured once per CPU model by tools/cpu_fullsize.py and kept under profiles/, not re-run by every bench)
+    try:
+        fj = json.load(open(os.path.join(ROOT, "profiles", "cpu_fullsize_%s.json" % w)))
+        for rec in fj["runs"]:
+            if rec["max_iter"] == wl.max_iter and rec["obstacles"] == wl.M:
+                out["full_size_single_thread"] = dict(rec, same_cpu_model=(rec.get("cpu_model") == out["cpu_model"]))
+                break
+    except (OSError, ValueError, KeyError):
+        pass
     return out
 
 
@@ -379,7 +419,7 @@ class DryHandle:
         n = self.B * self.max_iter
         return dict(iterations=n, edges_unique=10 * n, edges_ref=100 * n, algorithmic_bytes=1000 * n,
                     algorithmic_bytes_two_scan=8000 * n, kernel_ms=20.0, launches=1, near_unique_max=0, f32_fallbacks=0,
-                    q16_fallbacks=0, exact_rescans=0)
+                    q16_fallbacks=0, exact_rescans=0, replanned=0, main_shape=64, main_f32=1)
 
     def get_results(self):
         import numpy as np
@@ -449,13 +489,25 @@ def main():
                  last_stats={}, printed=False, results=None)
     metric, workload_name, kernel_name = wl.names()
 
+    def kernel_of(stats):
+        """Name of the dominant kernel as rrtx_plan really launched it (C2: the workgroup shape is picked from the
+        instance count, the obstacle count, the estimated near-set size and RRTX_TPB -- rrtx_stats.main_shape)."""
+        if a.workload != "c2":
+            return kernel_name
+        ns = {64: "rppk2t", 128: "rppk2s", 256: "rppk2"}.get(int(stats.get("main_shape", 0) or 0))
+        return "%s::rrt_star_kernel_v2<%s>" % (ns, "true" if stats.get("main_f32", 1) else "false") if ns else kernel_name
+
     def build_line(h, final):
         """The JSON line for the steps completed so far (cross-rank reductions only when `final`)."""
         sd = max(state["steps_done"], 1)
         dt = state["dt"]
         pc, nn, st = state["results"]     # table of the last completed step (never read while a plan is running)
+        per_rank = None
         if final:
             tmax = sharding.reduce_max(dist, dt, cuda)
+            # per-rank clocks, so that a scaling run explains its own efficiency: wall time of the timed region and the
+            # dominant kernel's HIP-event time on every rank (the job's clock is the max)
+            per_rank = sharding.gather_floats(dist, [dt, state["kms_main"] / 1e3], cuda)
             tot_eu, tot_er, tot_it = sharding.reduce_sum_int(dist, [state["eu"], state["er"], state["iters"]], cuda)
             all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda,
                                                              device_table=None if a.dry_run else h)
@@ -476,7 +528,7 @@ def main():
         achieved_2s = (alg2 / 1e9) / (kms / 1e3) if kms > 0 and alg2 > 0 else None
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS if achieved else None, "traffic": None, "traffic_frac": None,
-                "kernel": kernel_name, "launches": state["launches_main"],
+                "kernel": kernel_of(state["last_stats"]), "launches": state["launches_main"],
                 "kernel_ms_per_step": kms / sd, "kernel_ms_per_launch": kms / nl_main,
                 "kernel_ms_all_per_step": state["kernel_ms"] / sd,
                 "algorithmic_bytes_per_step": alg / sd, "algorithmic_bytes_per_launch": alg / nl_main,
@@ -489,7 +541,7 @@ def main():
                                                "iteration) applied to the same run: an EQUIVALENT rate, not bytes moved")
         # HBM traffic from separate rocprofv3 --pmc passes of this exact device code (tools/profile_headline.sh writes
         # profiles/r2_*_traffic.json with the hash of csrc/ it measured)
-        tfile = os.path.join(ROOT, "profiles", "r2_%s_traffic.json" % a.workload)
+        tfile = profile_file("%s_traffic.json" % a.workload)
         try:
             tj = json.load(open(tfile))
             tc = tj["config"]
@@ -512,15 +564,26 @@ def main():
         # dependent-instruction latency, not by HBM.  Their roof is the VALU issue rate, measured by a rocprofv3 --pmc
         # pass of this exact device code (tools/valu_pass.sh -> profiles/r2_<workload>_valu.json); the HBM figures stay
         # next to it under "hbm".
-        vfile = os.path.join(ROOT, "profiles", "r2_%s_valu.json" % a.workload)
+        vfile = profile_file("%s_valu.json" % a.workload)
         if a.workload != "c2":
             try:
                 vj = json.load(open(vfile))
             except (OSError, ValueError):
                 vj = None
             if vj is not None and vj.get("csrc_hash") == csrc_hash(a.workload):
-                roof = {"bound": "valu", "achieved": 100.0 * vj["valu_busy_frac"], "peak": 100.0,
-                        "unit": "% of VALU issue slots", "frac": vj["valu_busy_frac"], "traffic": None,
+                # issue cycles per launch from the counters (a property of the code and the workload), over THIS run's
+                # kernel time: the profiled run's own time is inflated by counter collection (its figure stays beside it)
+                cn = vj.get("counters", {})
+                f64i = sum(cn.get(k, 0.0) for k in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64",
+                                                    "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64"))
+                disp = max(vj.get("dispatches", 1), 1)
+                issue = (2.0 * (cn.get("SQ_INSTS_VALU", 0.0) - f64i) + 4.0 * f64i) / disp
+                vfrac = vj["valu_busy_frac"]
+                if issue > 0 and kms > 0:
+                    vfrac = issue * nl_main / (kms * 1e-3 * 2.4e9 * 1024.0)
+                roof = {"bound": "valu", "achieved": 100.0 * vfrac, "peak": 100.0,
+                        "unit": "% of VALU issue slots", "frac": vfrac, "traffic": None,
+                        "frac_in_profiled_run": vj["valu_busy_frac"], "issue_cycles_per_launch": issue,
                         "kernel": kernel_name, "launches": state["launches_main"], "kernel_ms_per_step": kms / sd,
                         "kernel_ms_per_launch": kms / nl_main,
                         "valu_insts_per_launch": vj.get("valu_insts_per_launch"),
@@ -528,7 +591,7 @@ def main():
                         "f64_flops_upper_TFLOPs": vj.get("f64_flops_upper_TFLOPs"), "f64_peak_TFLOPs": 78.6,
                         "note": "VALU-issue roofline from rocprofv3 --pmc SQ_INSTS_VALU / _FMA_F64 / _ADD_F64 / _MUL_F64 / "
                                 "_TRANS_F64 of this device code (profiles/%s, commit %s): frac = (2 cycles x non-f64 + 4 cycles x "
-                                "f64 VALU instructions) / (kernel time x 2.4 GHz x 1024 SIMDs).  The kernel is latency bound "
+                                "f64 VALU instructions per launch) x launches / (THIS run's kernel time x 2.4 GHz x 1024 SIMDs).  The kernel is latency bound "
                                 "(dependent f64 chains of the libm replicas on few lanes: active_lane_frac), HBM is idle"
                                 % (os.path.basename(vfile), vj.get("commit")),
                         "hbm": roof}
@@ -600,6 +663,16 @@ def main():
         if c4:
             line["unit"] = "edge expansions/s"
             roof["note"] += "; BIT* is an instance-parallel sequential search (one wave per instance, state in LDS)"
+        if per_rank is not None:
+            wall = [1e3 * r[0] / sd for r in per_rank]
+            kern = [1e3 * r[1] / sd for r in per_rank]
+            line["per_rank"] = {"ms_per_step": wall, "kernel_ms_per_step": kern,
+                                "ms_per_step_min": min(wall), "ms_per_step_max": max(wall),
+                                "ms_per_step_mean": sum(wall) / len(wall),
+                                "imbalance": max(wall) / (sum(wall) / len(wall)) if sum(wall) > 0 else None,
+                                "note": "rank r plans instances r*B .. (r+1)*B-1; the job's ms_per_step is the max over "
+                                        "ranks; imbalance = max / mean (1.0 = every GPU finished its shard together)"}
+        line["replanned_last_step"] = ls.get("replanned", 0)
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if os.environ.get("RRTX_BENCH_SHARE_GPU"):

@@ -25,8 +25,9 @@
 extern "C" {
 #endif
 
-#define RRTX_ABI_VERSION 3   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
-                                rrtx_copy_results_device, per-instance yaw and informed rotation */
+#define RRTX_ABI_VERSION 4   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
+                                rrtx_copy_results_device, per-instance yaw and informed rotation; 4: rrtx_plan_many,
+                                rrtx_selfcheck, rrtx_stats.main_shape / main_f32 */
 
 enum {
   RRTX_PARTIAL = 1,        /* rrtx_plan only: the call completed, but at least one instance stopped with RRTX_ST_OVERFLOW,
@@ -128,7 +129,10 @@ typedef struct rrtx_stats {
   int64_t replanned;         /* instances planned a second time from their staged start state: a near set that outgrew its
                                 workgroup shape's table, a polyline pool that ran out, or an rrt_04 rewire that moved a
                                 node while near_inds held repeated indices (raw-list walk of the general kernel) */
-  int64_t reserved[1];
+  int32_t main_shape;        /* threads per workgroup (= per planning instance) of the dominant kernel as launched:
+                                RRTX_ALGO_RRT_STAR iteration kernel 64 / 128 / 256 (picked from the instance count, the
+                                obstacle count, the estimated near-set size and RRTX_TPB); the other planners' fixed shape */
+  int32_t main_f32;          /* RRTX_ALGO_RRT_STAR iteration kernel: 1 = f32-mirror instantiation (<true>), 0 = f64 passes */
 } rrtx_stats;
 
 typedef struct rrtx_handle rrtx_handle;
@@ -155,6 +159,13 @@ int rrtx_set_instance_rotation(rrtx_handle* h, int32_t instance, const double* r
 /* replaces the body of RRT.planning(animation=False) for every instance; blocking.  Returns RRTX_OK, RRTX_PARTIAL
  * (see above) or a negative error. */
 int rrtx_plan(rrtx_handle* h);
+/* Multi-GPU in one process ("one handle per device, driven from one process with N threads"): plans the n
+ * handles concurrently, one host thread per handle (each bound to its handle's device; two handles may share a device),
+ * and returns when all have finished.  rcs[i] (may be NULL) = what rrtx_plan(handles[i]) returned; the return value is
+ * the most severe of them (a negative error, else RRTX_PARTIAL, else RRTX_OK).  Instances are independent, so sharding a
+ * batch over handles changes no result: instance j of handle i is the instance it would be in one large handle with the
+ * same seed / start / goal.  The handles must be distinct. */
+int rrtx_plan_many(rrtx_handle** handles, int32_t n, int32_t* rcs);
 /* rrt.node_list as SoA: x, y, cost (f64), parent (i32, -1 = None); any pointer may be NULL. */
 int rrtx_get_tree(rrtx_handle* h, int32_t instance, double* x, double* y, double* cost, int32_t* parent,
                   int32_t cap, int32_t* n_out);

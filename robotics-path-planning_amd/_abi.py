@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
-RRTX_ABI_VERSION = 3
+RRTX_ABI_VERSION = 4
 ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR, ALGO_RRT_DUBINS, ALGO_RS = 0, 1, 2, 3, 4, 5, 6
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
 ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC, ST_UNSUPPORTED, ST_REF_RAISES = 1, 2, 4, 8, 16, 32
@@ -25,7 +25,7 @@ EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obs
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_copy_results_device", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_trace_kind", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
-           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw", "rrtx_selfcheck"]
+           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw", "rrtx_selfcheck", "rrtx_plan_many"]
 
 
 class Params(C.Structure):
@@ -50,7 +50,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("algorithmic_bytes_two_scan", C.c_int64),
                 ("near_unique_max", C.c_int64), ("f32_fallbacks", C.c_int64), ("q16_fallbacks", C.c_int64),
                 ("launches_main", C.c_int64), ("kernel_ms_main", C.c_double), ("replanned", C.c_int64),
-                ("reserved", C.c_int64 * 1)]
+                ("main_shape", C.c_int32), ("main_f32", C.c_int32)]
 
 
 class RrtxError(RuntimeError):
@@ -103,6 +103,7 @@ def load():
     L.rrtx_get_smoothed_path.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.rrtx_get_path_yaw.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.rrtx_selfcheck.argtypes = [i32, i32, vp]
+    L.rrtx_plan_many.argtypes = [vp, i32, vp]
     for f in EXPORTS:
         if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
             getattr(L, f).restype = C.c_int
@@ -374,6 +375,23 @@ class Handle:
         kind = np.zeros(cap, dtype=np.int32)
         self._chk(self.L.rrtx_get_trace_kind(self._h, kind.ctypes.data, cap, C.byref(n)), "rrtx_get_trace_kind")
         return kind[:n.value]
+
+
+def plan_many(handles, strict=False):
+    """rrtx_plan_many: plans the handles concurrently, one native host thread each (one handle per device = multi-GPU in
+    one process).  Returns the per-handle return codes (0 / RRTX_PARTIAL); raises on an error of any of them."""
+    L = load()
+    n = len(handles)
+    arr = (C.c_void_p * n)(*[h._h for h in handles])
+    rcs = (C.c_int32 * n)()
+    rc = L.rrtx_plan_many(C.cast(arr, C.c_void_p), n, C.cast(rcs, C.c_void_p))
+    for h, r in zip(handles, rcs):
+        h._chk(int(r), "rrtx_plan_many")
+    if rc < 0:
+        raise RrtxError("rrtx_plan_many: %s" % ERRORS.get(rc, rc))
+    if strict and rc == RRTX_PARTIAL:
+        raise RrtxError("rrtx_plan_many: %s" % "; ".join(h.last_error() for h, r in zip(handles, rcs) if r == RRTX_PARTIAL))
+    return [int(r) for r in rcs]
 
 
 def smooth_paths(paths, max_iter, obstacles, rng_states, device=0):

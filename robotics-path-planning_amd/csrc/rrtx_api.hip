@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrtx.h"
@@ -72,6 +73,13 @@ struct rrtx_handle {
     int64_t cap = 0, slab = 0;
   };
   std::vector<PoolLoc> pool_loc;
+  // the enlarged pools of the overflow re-plan (x4, x16): kept on the handle and used again by later rrtx_plan calls
+  // when they are large enough (slabs >= instances to re-plan), so repeated plans do not grow device memory
+  struct BigPool {
+    double *px = nullptr, *py = nullptr, *pyaw = nullptr;
+    int64_t cap = 0;
+    int slabs = 0;
+  } big[2];
   int32_t* pool_slot = nullptr;  // device copy of the slab numbers of a re-plan
   int64_t stats_retried = 0;
   int informed_eager = 0;        // rrt_07 kernel: 1 = collision-test every near candidate (reference order), 0 = cheapest first
@@ -181,6 +189,11 @@ void rrtx_destroy(rrtx_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
   for (void* q : h->allocs) hipFree(q);
+  for (auto& bp : h->big) {
+    if (bp.px) hipFree(bp.px);
+    if (bp.py) hipFree(bp.py);
+    if (bp.pyaw) hipFree(bp.pyaw);
+  }
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
   if (h->stream) hipStreamDestroy(h->stream);
@@ -736,19 +749,28 @@ int rrtx_plan(rrtx_handle* h) {
       if (redo.empty()) break;
       const int nr = (int)redo.size();
       big_cap *= 4;
-      double *bx = nullptr, *by = nullptr, *bw = nullptr;
-      const size_t bytes = sizeof(double) * (size_t)big_cap * nr;
-      if (hipMalloc((void**)&bx, bytes) != hipSuccess || hipMalloc((void**)&by, bytes) != hipSuccess ||
-          (c.algo == RRTX_ALGO_RS && hipMalloc((void**)&bw, bytes) != hipSuccess)) {
-        (void)hipGetLastError();   // no room for the larger pool: the instances keep their RRTX_ST_OVERFLOW
-        if (bx) hipFree(bx);
-        if (by) hipFree(by);
-        if (bw) hipFree(bw);
-        break;
+      rrtx_handle::BigPool& bp = h->big[attempt];
+      if (bp.cap != big_cap || bp.slabs < nr) {
+        // (re)allocate this level: nothing of the CURRENT plan lives in it yet (its users are decided below), and the
+        // previous plan's polylines are gone with the re-initialisation above
+        if (bp.px) hipFree(bp.px);
+        if (bp.py) hipFree(bp.py);
+        if (bp.pyaw) hipFree(bp.pyaw);
+        bp = rrtx_handle::BigPool();
+        const size_t bytes = sizeof(double) * (size_t)big_cap * nr;
+        if (hipMalloc((void**)&bp.px, bytes) != hipSuccess || hipMalloc((void**)&bp.py, bytes) != hipSuccess ||
+            (c.algo == RRTX_ALGO_RS && hipMalloc((void**)&bp.pyaw, bytes) != hipSuccess)) {
+          (void)hipGetLastError();   // no room for the larger pool: the instances keep their RRTX_ST_OVERFLOW
+          if (bp.px) hipFree(bp.px);
+          if (bp.py) hipFree(bp.py);
+          if (bp.pyaw) hipFree(bp.pyaw);
+          bp = rrtx_handle::BigPool();
+          break;
+        }
+        bp.cap = big_cap;
+        bp.slabs = nr;
       }
-      h->allocs.push_back(bx);
-      h->allocs.push_back(by);
-      if (bw) h->allocs.push_back(bw);
+      double *bx = bp.px, *by = bp.py, *bw = bp.pyaw;
       int rc2;
       if (!h->inst_map && (rc2 = dalloc(h, &h->inst_map, B))) return rc2;
       if (!h->pool_slot && (rc2 = dalloc(h, &h->pool_slot, B))) return rc2;
@@ -884,6 +906,13 @@ int rrtx_plan(rrtx_handle* h) {
   s.launches_main = kms_main >= 0.0 ? launches_main : launches;
   s.kernel_ms_main = kms_main >= 0.0 ? kms_main : kms;
   s.replanned = h->stats_retried;
+  s.main_shape = use_v2 ? v2_tpb
+                        : c.algo == RRTX_ALGO_INFORMED ? rppi::TPB
+                        : is_dubins(c.algo)            ? rppd::TPB
+                        : c.algo == RRTX_ALGO_RS       ? rppr::TPB
+                        : c.algo == RRTX_ALGO_BITSTAR  ? 64
+                                                       : rppk::TPB;
+  s.main_f32 = use_v2 ? (v2_f32 ? 1 : 0) : 0;
   s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   h->planned = true;
   // Per-instance conditions are per-instance results: the status word of each instance carries them
@@ -1398,6 +1427,31 @@ int rrtx_selfcheck(int32_t device, int32_t n_per_fn, int64_t* mismatches8) {
     mismatches8[f] = bad;
   }
   return RRTX_OK;
+}
+
+int rrtx_plan_many(rrtx_handle** handles, int32_t n, int32_t* rcs) {
+  if (!handles || n < 1) return RRTX_E_INVALID;
+  for (int i = 0; i < n; i++)
+    if (!handles[i]) return RRTX_E_INVALID;
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < i; j++)
+      if (handles[i] == handles[j]) return RRTX_E_INVALID;   // a handle is not thread safe
+  std::vector<int> rc(n, RRTX_OK);
+  if (n == 1) {
+    rc[0] = rrtx_plan(handles[0]);
+  } else {
+    std::vector<std::thread> th;
+    th.reserve(n);
+    for (int i = 0; i < n; i++) th.emplace_back([&rc, handles, i]() { rc[i] = rrtx_plan(handles[i]); });
+    for (auto& t : th) t.join();
+  }
+  int worst = RRTX_OK;
+  for (int i = 0; i < n; i++) {
+    if (rcs) rcs[i] = rc[i];
+    if (rc[i] < 0 && (worst >= 0 || rc[i] < worst)) worst = rc[i];
+    else if (rc[i] == RRTX_PARTIAL && worst == RRTX_OK) worst = RRTX_PARTIAL;
+  }
+  return worst;
 }
 
 }  // extern "C"

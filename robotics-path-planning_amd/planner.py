@@ -625,16 +625,22 @@ def get_path_length(path):
 
 
 class BatchPlanner:
-    """Many independent planning instances (seeds / start-goal pairs) on one GPU.
+    """Many independent planning instances (seeds / start-goal pairs) on one GPU or sharded over several.
 
     This is the throughput form of the same kernels: instance i consumes the stream of
     `random.seed(seeds[i])` and produces exactly the tree the single-instance class would.
-    """
+
+    `devices=[d0, d1, ...]` ("one handle per device, driven from one process with N threads"): the batch is cut
+    into len(devices) contiguous blocks (`sharding.split_contiguous`), one handle per entry, planned concurrently by
+    `rrtx_plan_many` (one native host thread per handle; no torch, no collective -- instances never communicate) and
+    read back as ONE batch: every accessor takes the global instance index.  A device may be listed more than once
+    (two handles sharing a GPU), which is also how the sharding is tested on a one-GPU box.  Results do not depend on
+    the sharding."""
 
     def __init__(self, algo, seeds, start, goal, obstacle_list, rand_area, expand_dis=3.0, path_resolution=0.5,
                  goal_sample_rate=5, max_iter=500, play_area=None, robot_radius=0.0, sobol_sampler=False,
                  connect_circle_dist=50.0, search_until_max_iter=False, device=0, starts=None, goals=None,
-                 curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.2):
+                 curvature=1.0, goal_yaw_th=float(np.deg2rad(1.0)), goal_xy_th=0.5, step_size=0.2, devices=None):
         """algo: "rrt" (rrt_01/02), "rrt_star" (rrt_04), "informed" (rrt_07: expand_dis, goal_sample_rate, max_iter,
         sobol_sampler as in its constructor :1029-1042), "bitstar" (rrt_08: max_iter = maxIter, rand_area = randArea
         :140-168), and the pose planners (start / goal = [x, y, yaw]; curvature, goal thresholds and, for Reeds-Shepp,
@@ -642,7 +648,9 @@ class BatchPlanner:
         "rrt_star_reeds_shepp" (rrt_06).
         `starts` / `goals`: per-instance [x, y] (pose planners: [x, y, yaw]; a missing yaw keeps `start[2]` /
         `goal[2]`).  For "informed" and "bitstar" the rotation to the world frame and c_min (rrt_07:1054-1068,
-        rrt_08:189-202) are computed per instance on the host with numpy, as the reference does per planner object."""
+        rrt_08:189-202) are computed per instance on the host with numpy, as the reference does per planner object.
+        `devices`: HIP device ordinals to shard over (default: [device])."""
+        from . import sharding
         a = {"rrt": _abi.ALGO_RRT, "rrt_star": _abi.ALGO_RRT_STAR, "rrt_dubins": _abi.ALGO_RRT_DUBINS,
              "rrt_star_dubins": _abi.ALGO_DUBINS, "rrt_star_reeds_shepp": _abi.ALGO_RS, "informed": _abi.ALGO_INFORMED,
              "bitstar": _abi.ALGO_BITSTAR}[algo]
@@ -650,86 +658,133 @@ class BatchPlanner:
         self.pose = a in (_abi.ALGO_RRT_DUBINS, _abi.ALGO_DUBINS, _abi.ALGO_RS)
         self.algo = a
         n = len(self.seeds)
+        self.devices = [int(device)] if devices is None else [int(d) for d in devices]
+        if not self.devices or n < len(self.devices):
+            raise ValueError("BatchPlanner: %d instances cannot be sharded over %d handles" % (n, len(self.devices)))
+        self.shards = sharding.split_contiguous(n, len(self.devices))
         rot_of = {_abi.ALGO_INFORMED: informed_rotation, _abi.ALGO_BITSTAR: bitstar_rotation}.get(a)
-        if a == _abi.ALGO_INFORMED:
-            c_min, c = informed_rotation(start, goal)
-            self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, 1.0, goal_sample_rate, max_iter,
-                                 sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT, n_instances=n,
-                                 device=device, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
-        elif a == _abi.ALGO_BITSTAR:
-            c_min, c = bitstar_rotation(start, goal)
-            self.h = _abi.Handle(a, start, goal, rand_area, 2.0, 1.0, 0, max_iter, n_instances=n, device=device,
-                                 informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
-        else:
-            self.h = _abi.Handle(a, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
-                                 play_area=play_area, robot_radius=robot_radius,
-                                 sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT,
-                                 connect_circle_dist=connect_circle_dist, search_until_max_iter=search_until_max_iter,
-                                 n_instances=n, device=device, curvature=curvature, goal_yaw_th=goal_yaw_th,
-                                 goal_xy_th=goal_xy_th, step_size=step_size)
-        self.h.set_obstacles(obstacle_list)
-        self.h.seed_instances(self.seeds)
-        if starts is not None or goals is not None:
-            for i in range(n):
-                si = start if starts is None else starts[i]
-                gi = goal if goals is None else goals[i]
-                self.h.set_instance(i, None if starts is None else si, None if goals is None else gi)
-                if rot_of is not None:
-                    cm, ci = rot_of(si, gi)
-                    self.h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        self.handles = []
+        try:
+            for dev, (lo, hi) in zip(self.devices, self.shards):
+                if a == _abi.ALGO_INFORMED:
+                    c_min, c = informed_rotation(start, goal)
+                    h = _abi.Handle(a, start, goal, rand_area, expand_dis, 1.0, goal_sample_rate, max_iter,
+                                    sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT, n_instances=hi - lo,
+                                    device=dev, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+                elif a == _abi.ALGO_BITSTAR:
+                    c_min, c = bitstar_rotation(start, goal)
+                    h = _abi.Handle(a, start, goal, rand_area, 2.0, 1.0, 0, max_iter, n_instances=hi - lo, device=dev,
+                                    informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+                else:
+                    h = _abi.Handle(a, start, goal, rand_area, expand_dis, path_resolution, goal_sample_rate, max_iter,
+                                    play_area=play_area, robot_radius=robot_radius,
+                                    sampler=_abi.SAMPLER_SOBOL if sobol_sampler else _abi.SAMPLER_MT,
+                                    connect_circle_dist=connect_circle_dist, search_until_max_iter=search_until_max_iter,
+                                    n_instances=hi - lo, device=dev, curvature=curvature, goal_yaw_th=goal_yaw_th,
+                                    goal_xy_th=goal_xy_th, step_size=step_size)
+                self.handles.append(h)
+                h.set_obstacles(obstacle_list)
+                h.seed_instances(self.seeds[lo:hi])
+                if starts is not None or goals is not None:
+                    for i in range(lo, hi):
+                        si = start if starts is None else starts[i]
+                        gi = goal if goals is None else goals[i]
+                        h.set_instance(i - lo, None if starts is None else si, None if goals is None else gi)
+                        if rot_of is not None:
+                            cm, ci = rot_of(si, gi)
+                            h.set_instance_rotation(i - lo, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        except Exception:
+            self.close()
+            raise
+        self.h = self.handles[0]      # the single-device form's handle (kept for callers that reach for it)
         self.partial = False
+
+    def _loc(self, i):
+        """(handle, local index) of global instance i."""
+        if i < 0:
+            i += len(self.seeds)
+        for h, (lo, hi) in zip(self.handles, self.shards):
+            if lo <= i < hi:
+                return h, i - lo
+        raise IndexError(i)
 
     def plan(self):
         """Plans every instance; returns (path_cost, n_nodes, status) per instance.  An instance that stopped on a
         capacity limit or where the reference would raise carries the bit in its status word (`failed()` lists
         them); the other instances are complete.  Raises only for errors of the call as a whole."""
-        self.partial = self.h.plan() == _abi.RRTX_PARTIAL
-        return self.h.get_results()
+        rcs = _abi.plan_many(self.handles)
+        self.partial = any(r == _abi.RRTX_PARTIAL for r in rcs)
+        return self.results()
+
+    def results(self):
+        """(path_cost, n_nodes, status) of the whole batch, shards concatenated in instance order."""
+        parts = [h.get_results() for h in self.handles]
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
 
     def failed(self):
         """Indices of the instances without a result after plan(), with their status words."""
-        _, _, st = self.h.get_results()
+        _, _, st = self.results()
         return [(int(i), int(st[i])) for i in np.nonzero(st & _abi.ST_FAILED)[0]]
 
     def stats(self):
-        return self.h.get_stats()
+        """rrtx_stats summed over the shards (times: the slowest shard's; maxima: the largest)."""
+        per = [h.get_stats() for h in self.handles]
+        if len(per) == 1:
+            return per[0]
+        out = {}
+        for k in per[0]:
+            v = [p[k] for p in per]
+            out[k] = max(v) if k in ("kernel_ms", "plan_ms", "kernel_ms_main", "near_unique_max", "main_shape", "main_f32") else sum(v)
+        out["per_shard"] = per
+        return out
 
     def tree(self, i):
-        return self.h.get_tree(i)
+        h, j = self._loc(i)
+        return h.get_tree(j)
 
     def path(self, i):
         """The course `planning()` returns: (n, 2), or (n, 3) with the yaw column for "rrt_star_reeds_shepp"."""
-        p = self.h.get_path(i)
+        h, j = self._loc(i)
+        p = h.get_path(j)
         if p is not None and self.algo == _abi.ALGO_RS:
-            p = np.column_stack([p, self.h.get_path_yaw(i)])
+            p = np.column_stack([p, h.get_path_yaw(j)])
         return p
 
     def yaw(self, i):
-        return self.h.get_yaw(i)
+        h, j = self._loc(i)
+        return h.get_yaw(j)
 
     def polylines(self, i):
-        return self.h.get_polylines(i)
+        h, j = self._loc(i)
+        return h.get_polylines(j)
+
+    def rng_state(self, i):
+        h, j = self._loc(i)
+        return h.get_rng_state(j)
 
     def smooth(self, max_iter):
         """path_smoothing(path, max_iter, obstacle_list) (rrt_04:1447-1479) on every planned path, on the device, each
         instance continuing its own random stream (as the driver does at :1558-1559)."""
-        self.h.smooth_planned(max_iter)
-        return [self.h.get_smoothed_path(i) for i in range(len(self.seeds))]
+        for h in self.handles:
+            h.smooth_planned(max_iter)
+        return [self._loc(i)[0].get_smoothed_path(self._loc(i)[1]) for i in range(len(self.seeds))]
 
     def export_npz(self, filename, instances=None):
         """Compact on-disk form of the planned trees for plotting / regression diffs: per instance
         (x, y, cost, parent) as the reference's node_list holds them, the returned path, path cost, seed."""
         ids = list(range(len(self.seeds))) if instances is None else list(instances)
-        pc, nn, st = self.h.get_results()
+        pc, nn, st = self.results()
         out = dict(seeds=np.array([self.seeds[i] for i in ids], dtype=np.int64), path_cost=pc[ids], n_nodes=nn[ids],
                    status=st[ids])
         for k, i in enumerate(ids):
-            x, y, cost, parent = self.h.get_tree(i)
-            p = self.h.get_path(i)
+            h, j = self._loc(i)
+            x, y, cost, parent = h.get_tree(j)
+            p = h.get_path(j)
             out["x_%d" % k], out["y_%d" % k], out["cost_%d" % k], out["parent_%d" % k] = x, y, cost, parent
             out["path_%d" % k] = np.zeros((0, 2)) if p is None else p
         np.savez_compressed(filename, **out)
         return filename
 
     def close(self):
-        self.h.close()
+        for h in getattr(self, "handles", []):
+            h.close()

@@ -85,3 +85,28 @@ def all_agree_min(dist, flag, device=None):
         t = t.to(device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
+
+
+def gather_floats(dist, values, device=None):
+    """all_gather of a short float vector per rank; returns [[values of rank 0], [values of rank 1], ...]."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [[float(v) for v in values]]
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [[float(v) for v in o.cpu().tolist()] for o in out]
+
+
+def split_contiguous(n, shards):
+    """[lo, hi) of each of `shards` contiguous blocks of n instances, sizes differing by at most one (the first n %
+    shards blocks are the longer ones); instance i of the whole batch is instance i - lo of its shard."""
+    base, extra = divmod(int(n), int(shards))
+    out, lo = [], 0
+    for r in range(int(shards)):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out

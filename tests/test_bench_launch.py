@@ -30,6 +30,22 @@ def test_bench_self_launches_its_ranks():
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["dry_run"] is True and j["value"] is None
     assert j["instances_total"] == 2 * j["config"]["instances_per_gpu"]      # both shards were gathered
     assert j["config"]["workload"].startswith("C2:") and "roofline" in j
+    pr = j["per_rank"]                                                        # a scaling run explains its own efficiency
+    assert len(pr["ms_per_step"]) == 2 and len(pr["kernel_ms_per_step"]) == 2
+    assert pr["ms_per_step_max"] == max(pr["ms_per_step"]) and pr["ms_per_step_min"] == min(pr["ms_per_step"])
+    assert abs(j["ms_per_step"] - pr["ms_per_step_max"]) < 1e-6 * max(1.0, j["ms_per_step"]) and pr["imbalance"] >= 1.0
+
+
+def test_bench_eight_rank_dry_run_line_carries_the_per_rank_fields():
+    """The driver's 8-GPU form rehearsed without devices: 8 self-launched ranks over gloo, one line, 8 per-rank clocks."""
+    r = _run(["--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "0"], timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    pr = j["per_rank"]
+    assert j["n_gpus"] == 8 and j["instances_total"] == 8 * j["config"]["instances_per_gpu"]
+    assert len(pr["ms_per_step"]) == 8 and pr["imbalance"] >= 1.0 and pr["ms_per_step_mean"] > 0
 
 
 def test_bench_under_a_launcher_environment():

@@ -1238,3 +1238,58 @@ def test_gpu_polyline_pool_overflow_is_replanned_with_a_larger_pool(gpu, monkeyp
         assert np.array_equal(bp.path(0), g6["path"]) and np.array_equal(bp.yaw(0), g6["yaw"])
     finally:
         bp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["rrt_star", "informed", "bitstar"])
+def test_batch_planner_sharded_over_handles_equals_one_handle(gpu, algo):
+    """BatchPlanner(devices=[0, 0, 0]): three handles on device 0, planned concurrently by rrtx_plan_many (one native host
+    thread per handle -- the single-process multi-GPU form) against ONE handle holding the whole batch: result
+    table, trees, paths and RNG states equal bit for bit, instance by instance (the sharding changes no result)."""
+    import random as _r
+    import rrt_amd
+    n = 25                                             # uneven split: 9 + 8 + 8
+    seeds = list(range(101, 101 + n))
+    kw = dict(seeds=seeds)
+    if algo == "rrt_star":
+        c2 = util.c2_kwargs(1500)
+        kw.update(start=c2["start"], goal=c2["goal"], obstacle_list=c2["obstacles"], rand_area=c2["rand_area"],
+                  expand_dis=2.0, path_resolution=0.25, goal_sample_rate=5, max_iter=1500, search_until_max_iter=True)
+    elif algo == "informed":
+        g = util.load_golden(util.GOLDEN + "/rrt07_drv_mt_s42_it2000.npz")
+        k7 = util.informed_kwargs_from_golden(g)
+        rr = _r.Random(3)
+        kw.update(start=k7["start"], goal=k7["goal"], obstacle_list=k7["obstacles"], rand_area=k7["rand_area"],
+                  expand_dis=0.5, goal_sample_rate=10, max_iter=600,
+                  goals=[[k7["goal"][0] + rr.uniform(-0.5, 0.5), k7["goal"][1] + rr.uniform(-0.5, 0.5)] for _ in seeds])
+    else:
+        obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+        rr = _r.Random(4)
+
+        def free():
+            while True:
+                x, y = rr.uniform(-1, 14), rr.uniform(-1, 14)
+                if all((x - ox) ** 2 + (y - oy) ** 2 > (r + 0.2) ** 2 for ox, oy, r in obst):
+                    return [x, y]
+        kw.update(start=[-1.0, 0.0], goal=[3.0, 8.0], obstacle_list=obst, rand_area=[-2.0, 15.0], max_iter=80,
+                  starts=[free() for _ in seeds], goals=[free() for _ in seeds])
+    one = rrt_amd.BatchPlanner(algo, **kw)
+    many = rrt_amd.BatchPlanner(algo, devices=[0, 0, 0], **kw)
+    try:
+        assert [hi - lo for lo, hi in many.shards] == [9, 8, 8] and len(many.handles) == 3
+        r1 = one.plan()
+        r3 = many.plan()
+        for a, b in zip(r1, r3):
+            assert np.array_equal(a, b)
+        for i in range(n):
+            util.assert_tree_equal(many.tree(i), one.tree(i), "%s instance %d" % (algo, i))
+            p1, p3 = one.path(i), many.path(i)
+            assert (p1 is None) == (p3 is None) and (p1 is None or np.array_equal(p1, p3))
+            assert many.rng_state(i) == one.rng_state(i)
+        s1, s3 = one.stats(), many.stats()
+        for k in ("iterations", "edges_unique", "edges_ref", "total_nodes", "rewires"):
+            assert s1[k] == s3[k], k
+        assert len(s3["per_shard"]) == 3
+    finally:
+        one.close()
+        many.close()
