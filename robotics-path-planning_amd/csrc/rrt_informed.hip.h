@@ -48,7 +48,10 @@ struct ShIT {
   double red_best[NW], red_second[NW];
   int32_t red_idx[NW], wave_cnt[NW], wave_start[NW];
   double rx, ry, nx, ny, ex, ey, ncost, cbest, plen;
+  double rx2, ry2;          // sample of the NEXT iteration, drawn ahead without touching the RNG state (peek_sample)
+  rpp::Sobol sob, sob2;     // Sobol state (any thread may draw), and the state after the peeked draw
   int32_t flag, nu, nvalid, overflow, ecoll, npar, nrw;
+  int32_t pk_pos, pk_ok;    // MT19937 position after the peeked draw; 1 = the peek stayed inside the current 624-word block
 };
 
 // numpy `u.dot(w)` for 2-vectors on the golden box: fma(u1, w1, u0*w0)
@@ -188,6 +191,205 @@ struct InformedArgs {
   double c_min2;
 };
 
+// MT19937 read-ahead: the tempered words at mt[pos..] WITHOUT advancing or twisting the generator.  A draw that would run
+// past the current 624-word block sets `bad` (the caller then draws the ordinary way at the start of the next iteration).
+struct MTPeek {
+  const uint32_t* mt;
+  int32_t pos, bad;
+};
+__device__ __forceinline__ uint32_t mt_next(MTPeek* s) {
+  if (s->pos >= 624) {
+    s->bad = 1;
+    return 0u;
+  }
+  uint32_t y = s->mt[s->pos++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680U;
+  y ^= (y << 15) & 0xefc60000U;
+  y ^= (y >> 18);
+  return y;
+}
+__device__ __forceinline__ uint32_t mt_next(rpp::MT* s) { return rpp::mt_next(s); }
+template <class R>
+__device__ __forceinline__ double rnd01(R* s) {   // random.random(): rpp::mt_random over either generator view
+  const uint32_t a = mt_next(s) >> 5, b = mt_next(s) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+// informed_sample :1145-1159 (sample_unit_ball :1162-1171, sample_free_space(_sobol) :1173-1191) with best path length
+// `cb`; consumes `rng` / `sob` in the reference's order.  R = rpp::MT (the real draw) or MTPeek (read-ahead).
+template <class R>
+__device__ __forceinline__ void informed_sample(R* rng, rpp::Sobol* sob, double cb, const InformedArgs& ia, const Ctx& c,
+                                                double gx, double gy, double& rx, double& ry) {
+  if (cb < rpp::dinf()) {
+    const double r0 = cb / 2.0;
+    const double r1 = __builtin_sqrt(rpp::py_sq(cb) - ia.c_min2) / 2.0;          // :1147
+    double a = rnd01(rng), b = rnd01(rng);                                       // sample_unit_ball :1162-1171
+    if (b < a) {
+      const double t = a;
+      a = b;
+      b = t;
+    }
+    const double ang = 2 * 3.141592653589793 * a / b;
+    const double s0 = b * rpp_glibc_cos(ang), s1 = b * rpp_glibc_sin(ang);
+    const double t00 = ia.rot[0] * r0, t01 = ia.rot[1] * r1, t10 = ia.rot[2] * r0, t11 = ia.rot[3] * r1;
+    rx = __builtin_fma(t00, s0, t01 * s1) + ia.xc[0];                            // np.dot(np.dot(c, rl), x_ball) + x_center :1151
+    ry = __builtin_fma(t10, s0, t11 * s1) + ia.xc[1];
+  } else {
+    uint32_t r = mt_next(rng) >> 25;                                             // random.randint(0, 100) :1173-1191
+    while (r >= 101) r = mt_next(rng) >> 25;
+    if ((int)r > c.goal_sample_rate) {
+      if (c.sampler == 1) {
+        double q[2];
+        rpp::sobol_next(sob, q);
+        rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);
+        ry = c.rand_min + q[1] * (c.rand_max - c.rand_min);
+      } else {
+        const double u0 = rnd01(rng);
+        rx = c.rand_min + (c.rand_max - c.rand_min) * u0;
+        const double u1 = rnd01(rng);
+        ry = c.rand_min + (c.rand_max - c.rand_min) * u1;
+      }
+    } else {
+      rx = gx;
+      ry = gy;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Streaming pass over the 16-bit coordinate mirror xq[] (4 bytes per node: x16 | y16 << 16, Ctx::xq; the scheme of
+// rrt_star_v2_body.inc scan2q, 256-thread shape): each wave streams a contiguous share with 16-byte non-temporal loads
+// (lane -> 4 adjacent nodes), a ring of QDI loads in flight per lane; squared distances are exact integers in grid units
+// (saturating 16-bit subtract + v_dot2_i32_i16).
+//   NEAR:    indices with grid distance**2 <= thr about the packed point qq, appended in ascending order to hits[]
+//            (wave w owns the slots starting at its range start; sh.wave_cnt / wave_start describe the segments);
+//   NEAREST: smallest and second smallest grid distance**2 to the packed point sq and the 4-node group (one load) the
+//            smallest came from; lowest group on ties.
+// Both are SUPERSET / candidate answers: the callers decide on the f64 coordinates.
+typedef uint32_t v4u_i __attribute__((ext_vector_type(4)));
+typedef short s2v_i __attribute__((ext_vector_type(2)));
+constexpr int QDI = 4;
+constexpr int QSLOT_I = 256;
+constexpr uint32_t QSAT_I = 32767u * 32767u;
+constexpr int NEWNODE = -2;   // "group" of a nearest answer that is the node appended after the pass
+__device__ __forceinline__ uint32_t qdist_i(uint32_t node, uint32_t query) {
+  const s2v_i d = __builtin_elementwise_sub_sat(__builtin_bit_cast(s2v_i, node), __builtin_bit_cast(s2v_i, query));
+  return (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+}
+__device__ __forceinline__ uint32_t umin3_i(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+__device__ __forceinline__ uint32_t umed3_i(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+
+template <bool NEAR, bool NEAREST, bool MASK>
+__device__ __forceinline__ void scan_q16_slot(const v4u_i v, const int i0, const int n, const uint32_t qq, const uint32_t thr,
+                                              const uint32_t sq, const uint64_t lt_mask, int32_t* __restrict__ hits,
+                                              const int ws, int& cnt, uint32_t& best, uint32_t& second, int& bgrp) {
+  if (NEAREST) {
+    uint32_t d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      d[j] = qdist_i(v[j], sq);
+      if (MASK) d[j] = (i0 + j < n) ? d[j] : 0xffffffffu;
+    }
+    const uint32_t b0 = best;
+    second = min(second, umed3_i(best, d[0], d[1]));
+    best = umin3_i(best, d[0], d[1]);
+    second = min(second, umed3_i(best, d[2], d[3]));
+    best = umin3_i(best, d[2], d[3]);
+    bgrp = best < b0 ? i0 : bgrp;
+  }
+  if (NEAR) {
+    bool hh[4];
+    uint64_t mm[4], any = 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      hh[j] = qdist_i(v[j], qq) <= thr && !(MASK && i0 + j >= n);
+      mm[j] = __ballot(hh[j]);
+      any |= mm[j];
+    }
+    if (any != 0ull) {
+      int pos = cnt, tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        pos += __popcll(mm[j] & lt_mask);
+        tot += __popcll(mm[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (hh[j]) hits[ws + pos++] = i0 + j;
+      cnt += tot;
+    }
+  }
+}
+
+template <bool NEAR, bool NEAREST, class SH>
+__device__ __forceinline__ int scan_q16(const uint32_t* __restrict__ xq, int n, uint32_t qq, uint32_t thr, uint32_t sq,
+                                        int32_t* __restrict__ hits, SH& sh, int& ggrp, uint32_t& gbest, uint32_t& gsecond) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int per = rppk::roundup_i((n + NW - 1) / NW, QSLOT_I);
+  const int ws = w * per;
+  const int wend = (ws + per < n) ? ws + per : n;
+  const int nsl = wend > ws ? (wend - ws + QSLOT_I - 1) / QSLOT_I : 0;   // slots of this wave
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int cnt = 0;
+  uint32_t best = 0xffffffffu, second = 0xffffffffu;
+  int bgrp = 0x7ffffffc;
+  if (nsl > 0) {
+    const v4u_i* pv = reinterpret_cast<const v4u_i*>(xq + ws) + lane;   // slot s = pv[64 * s]
+    const int last = nsl - 1;
+    const int rounds = (nsl + QDI - 1) / QDI;
+    v4u_i q[QDI];
+#pragma unroll
+    for (int u = 0; u < QDI; u++) q[u] = __builtin_nontemporal_load(pv + 64 * (u < last ? u : last));
+    int s0 = 0;
+    for (int r = 0; r + 1 < rounds; r++, s0 += QDI) {
+#pragma unroll
+      for (int u = 0; u < QDI; u++) {
+        const int sl = s0 + u;
+        scan_q16_slot<NEAR, NEAREST, false>(q[u], ws + sl * QSLOT_I + lane * 4, n, qq, thr, sq, lt_mask, hits, ws, cnt, best,
+                                            second, bgrp);
+        const int nx = sl + QDI;
+        q[u] = __builtin_nontemporal_load(pv + 64 * (nx < last ? nx : last));   // unconditional, clamped to the last slot
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < QDI; u++) {
+      const int sl = s0 + u;
+      if (sl < nsl)
+        scan_q16_slot<NEAR, NEAREST, true>(q[u], ws + sl * QSLOT_I + lane * 4, n, qq, thr, sq, lt_mask, hits, ws, cnt, best,
+                                           second, bgrp);
+    }
+  }
+  if (NEAR && lane == 0) {
+    sh.wave_cnt[w] = cnt;
+    sh.wave_start[w] = ws;
+  }
+  if (NEAREST) {
+    double gb, gs;
+    rppk::block_argmin((double)best, bgrp, (double)second, sh, gb, ggrp, gs);   // contains the barriers that publish wave_cnt
+    gbest = (uint32_t)gb;
+    gsecond = (uint32_t)gs;
+  } else {
+    __syncthreads();
+  }
+  int total = 0;
+  if (NEAR) {
+#pragma unroll
+    for (int k = 0; k < NW; k++) total += sh.wave_cnt[k];
+  }
+  return total;
+}
+
+// the node of the group [grp, grp + 4) whose grid distance to `sq` is `best` (lowest index); -1 when none matches
+__device__ __forceinline__ int resolve_group_i(const uint32_t* __restrict__ xq, int grp, int n, uint32_t sq, uint32_t best) {
+  int r = -1;
+#pragma unroll
+  for (int j = 3; j >= 0; j--)
+    if (grp + j < n && qdist_i(xq[grp + j], sq) == best) r = grp + j;
+  return r;
+}
+
 template <int NUI, int WPS>
 __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const InformedArgs* __restrict__ per_inst,
                                                                 double* cbest_io, int iters, int eager) {
@@ -211,6 +413,14 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
   float* __restrict__ yf = c.xf ? c.yf + off : nullptr;
   const double fm = c.f32_m, fmax = c.f32_m * 1048576.0;   // margin = 2^-20 * fmax
   int f32_ok = (c.xf != nullptr) && (I->first_goal != -3);
+  // 16-bit mirror (first stage of both queries, ONE pass per iteration): valid while every node lies inside the grid
+  // square [q_lo, q_hi]^2 (sampling square + margin, rrtx_api.hip); informed samples and the nodes that follow them may
+  // leave it, the instance then continues on the f32 / f64 passes for good (Inst::goal_dups = 1 carries that across launches)
+  uint32_t* __restrict__ xq = c.xq ? c.xq + off : nullptr;
+  int q16_ok = (c.xq != nullptr) && (I->goal_dups == 0);
+  const double q_glo = c.q_lo + c.q_step, q_ghi = c.q_lo + 65534.0 * c.q_step;
+  const double QMARGIN = 2.875 + 1e-6;   // 2 q_m in grid steps (q_m = 1.4375 steps) + slack for the two sqrt roundings
+  if (!(I->start[0] >= q_glo && I->start[0] <= q_ghi && I->start[1] >= q_glo && I->start[1] <= q_ghi)) q16_ok = 0;
 
   for (int i = tid; i < 624; i += TPB) sh.rng.mt[i] = I->rng.mt[i];
   for (int i = tid; i < c.m; i += TPB) {
@@ -223,12 +433,18 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
     sh.rng.pos = I->rng.pos;
     sh.overflow = 0;
     sh.cbest = cbest_io[inst];
+    sh.sob = I->sobol;
   }
   __syncthreads();
   int n = I->n, it = I->it;
   const double gx = I->goal[0], gy = I->goal[1], sx0 = I->start[0], sy0 = I->start[1];
   const double E = c.expand_dis;
-  rpp::Sobol sob = I->sobol;
+  // Read-ahead across iterations (never across launches): have_s = this iteration's sample was drawn during the previous
+  // one, have_n = its nearest query was answered by the previous iteration's pass: (p_best, p_second) grid distances,
+  // p_grp the 4-node group of the best (NEWNODE: the node appended after that pass)
+  int have_s = 0, have_n = 0, p_grp = 0;
+  uint32_t p_best = 0u, p_second = 0u;
+  int64_t s_qfb = 0;
   int64_t s_iter = 0, s_eu = 0, s_er = 0, s_nh = 0, s_nu = 0, s_rw = 0, s_sn = 0, s_ab = 0, s_ab2 = 0, s_ex = 0;
   int stop = 0;
   PH_DECL
@@ -236,85 +452,117 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
   for (int step = 0; step < iters && it < c.max_iter && !stop; step++, it++) {
     s_iter++;
     PH(15);
-    // ---------------- informed_sample :1145-1159
-    if (tid == 0) {
-      double rx, ry;
-      const double cb = sh.cbest;
-      if (cb < rpp::dinf()) {
-        const double r0 = cb / 2.0;
-        const double r1 = __builtin_sqrt(rpp::py_sq(cb) - ia.c_min2) / 2.0;          // :1147
-        double a = rpp::mt_random(&sh.rng), b = rpp::mt_random(&sh.rng);            // sample_unit_ball :1162-1171
-        if (b < a) {
-          const double t = a;
-          a = b;
-          b = t;
-        }
-        const double ang = 2 * 3.141592653589793 * a / b;
-        const double s0 = b * rpp_glibc_cos(ang), s1 = b * rpp_glibc_sin(ang);
-        const double t00 = ia.rot[0] * r0, t01 = ia.rot[1] * r1, t10 = ia.rot[2] * r0, t11 = ia.rot[3] * r1;
-        rx = __builtin_fma(t00, s0, t01 * s1) + ia.xc[0];                            // np.dot(np.dot(c, rl), x_ball) + x_center :1151
-        ry = __builtin_fma(t10, s0, t11 * s1) + ia.xc[1];
-      } else if (rpp::mt_randint_0_100(&sh.rng) > c.goal_sample_rate) {              // :1173-1191
-        if (c.sampler == 1) {
-          double q[2];
-          rpp::sobol_next(&sob, q);
-          rx = c.rand_min + q[0] * (c.rand_max - c.rand_min);
-          ry = c.rand_min + q[1] * (c.rand_max - c.rand_min);
-        } else {
-          rx = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
-          ry = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
-        }
-      } else {
-        rx = gx;
-        ry = gy;
+    // ---------------- informed_sample :1145-1159 (unless the previous iteration drew it ahead: sh.rx2 / ry2, committed there)
+    if (!have_s) {
+      if (tid == 0) {
+        double rx, ry;
+        informed_sample(&sh.rng, &sh.sob, sh.cbest, ia, c, gx, gy, rx, ry);
+        sh.rx = rx;
+        sh.ry = ry;
       }
-      sh.rx = rx;
-      sh.ry = ry;
+      __syncthreads();
     }
-    __syncthreads();
     const double rx = sh.rx, ry = sh.ry;
 
     PH(0);
     // ---------------- nearest :1210-1214
-    int ni;
-    double gbest, gsecond;
-    const bool q_ok = f32_ok && rpp::dabs(rx) <= fmax && rpp::dabs(ry) <= fmax;
+    int ni = -1;
+    double gbest = 1.0, gsecond = rpp::dinf();
     bool nearest_done = false;
-    if (q_ok) {
-      int fi;
-      double fb, fs;
-      rppk::scan_nearest_f32(xf, yf, n, (float)rx, (float)ry, sh, fi, fb, fs);
-      s_ab += 8 * (int64_t)n;
-      if (__builtin_sqrt(fs) - __builtin_sqrt(fb) > 2.0 * fm) {
-        ni = fi;
-        gbest = 1.0;
-        gsecond = rpp::dinf();
-        nearest_done = true;
+    {
+      // first stage on the 16-bit mirror: the prefetched answer, or a pass of its own
+      bool have_q = false;
+      uint32_t qb = 0u, qs = 0u, sq = 0u;
+      int qg = 0;
+      const bool s_in = rx >= q_glo && rx <= q_ghi && ry >= q_glo && ry <= q_ghi;
+      if (q16_ok && s_in) {
+        sq = rppk::quant16(c, rx, ry);
+        if (have_n) {
+          qb = p_best;
+          qs = p_second;
+          qg = p_grp;
+        } else {
+          scan_q16<false, true>(xq, n, 0u, 0u, sq, hits, sh, qg, qb, qs);
+          s_ab += 4 * (int64_t)n;
+        }
+        have_q = true;
+      }
+      if (have_q && qb < QSAT_I) {
+        // node and query each sit within half a grid step per coordinate of their true position: a true distance differs
+        // from the grid distance by less than q_m = 1.4375 steps, so the grid argmin is the true one when the runner-up is
+        // more than 2 q_m further; otherwise every node within 2 q_m of the best grid distance is a candidate and the
+        // decision is taken on the f64 coordinates with the reference's own expression (first minimum, :1212-1213)
+        const double rb = __builtin_sqrt((double)qb);
+        if (__builtin_sqrt((double)qs) - rb > QMARGIN) {
+          ni = (qg == NEWNODE) ? n - 1 : resolve_group_i(xq, qg, n, sq, qb);
+          nearest_done = ni >= 0;
+        }
+        if (!nearest_done) {
+          s_qfb++;
+          const double rr = rb + QMARGIN;
+          const double t2 = rr * rr * (1.0 + 1e-9) + 1.0;
+          const uint32_t thr2 = t2 >= 4294967295.0 ? 0xffffffffu : (uint32_t)t2;
+          int g0;
+          uint32_t b0, b1;
+          const int kraw = scan_q16<true, false>(xq, n, sq, thr2, 0u, hits, sh, g0, b0, b1);
+          s_ab += 4 * (int64_t)n + 16 * (int64_t)kraw;
+          double best = rpp::dinf(), second = rpp::dinf();
+          int bidx = 0x7fffffff;
+          for (int h = tid; h < kraw; h += TPB) {
+            const int idx = rppk::hit_at(hits, sh, h);
+            const double d = rpp::py_d2(x[idx] - rx, y[idx] - ry);
+            if (d < best || (d == best && idx < bidx)) {
+              best = d;
+              bidx = idx;
+            }
+          }
+          double gb2, gs2;
+          rppk::block_argmin(best, bidx, second, sh, gb2, ni, gs2);
+          nearest_done = ni >= 0 && ni < n;
+        }
       }
     }
     if (!nearest_done) {
-      rppk::scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
-      s_ab += 16 * (int64_t)n;
+      const bool q_ok = f32_ok && rpp::dabs(rx) <= fmax && rpp::dabs(ry) <= fmax;
+      bool f32_done = false;
+      if (q_ok) {
+        int fi;
+        double fb, fs;
+        rppk::scan_nearest_f32(xf, yf, n, (float)rx, (float)ry, sh, fi, fb, fs);
+        s_ab += 8 * (int64_t)n;
+        if (__builtin_sqrt(fs) - __builtin_sqrt(fb) > 2.0 * fm) {
+          ni = fi;
+          gbest = 1.0;
+          gsecond = rpp::dinf();
+          f32_done = true;
+        }
+      }
+      if (!f32_done) {
+        rppk::scan_nearest(x, y, n, rx, ry, sh, ni, gbest, gsecond);
+        s_ab += 16 * (int64_t)n;
+      }
+      if (gbest != 0.0 && gsecond <= gbest * (1.0 + FILTER_EPS)) {
+        s_ex++;
+        const int kraw = rppk::scan_hits(x, y, n, rx, ry, gbest * (1.0 + FILTER_EPS), hits, sh);
+        double best = rpp::dinf(), second = rpp::dinf();
+        int bidx = 0x7fffffff;
+        for (int h = tid; h < kraw; h += TPB) {
+          const int idx = rppk::hit_at(hits, sh, h);
+          const double d = rpp::py_d2(x[idx] - rx, y[idx] - ry);
+          if (d < best || (d == best && idx < bidx)) {
+            best = d;
+            bidx = idx;
+          }
+        }
+        double gb2, gs2;
+        rppk::block_argmin(best, bidx, second, sh, gb2, ni, gs2);
+      }
     }
     s_sn += n;
     s_ab += 24 * (int64_t)c.m;
     s_ab2 += 16 * (int64_t)n + 24 * (int64_t)c.m;
-    if (gbest != 0.0 && gsecond <= gbest * (1.0 + FILTER_EPS)) {
-      s_ex++;
-      const int kraw = rppk::scan_hits(x, y, n, rx, ry, gbest * (1.0 + FILTER_EPS), hits, sh);
-      double best = rpp::dinf(), second = rpp::dinf();
-      int bidx = 0x7fffffff;
-      for (int h = tid; h < kraw; h += TPB) {
-        const int idx = rppk::hit_at(hits, sh, h);
-        const double d = rpp::py_d2(x[idx] - rx, y[idx] - ry);
-        if (d < best || (d == best && idx < bidx)) {
-          best = d;
-          bidx = idx;
-        }
-      }
-      double gb2, gs2;
-      rppk::block_argmin(best, bidx, second, sh, gb2, ni, gs2);
-    }
+    have_s = 0;
+    have_n = 0;
 
     PH(1);
     // ---------------- steer :1080-1083 / get_new_node :1216-1224, extension edge :1085
@@ -333,7 +581,22 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       sh.ncost = cost[ni] + E;                                  // :1222
       sh.npar = ni;
       sh.ecoll = 0;
+    } else if (tid == 64 && step + 1 < iters && it + 1 < c.max_iter) {
+      // the sample of iteration it+1, read ahead on another wave while lane 0 steers: it depends on the RNG / Sobol state
+      // and on c_best only.  Nothing is consumed here; the draw is committed at the end of this iteration if c_best is
+      // still the value used (it changes only when this iteration's node connects to the goal with a shorter path)
+      MTPeek pk{sh.rng.mt, sh.rng.pos, 0};
+      rpp::Sobol sb = sh.sob;
+      double ax, ay;
+      informed_sample(&pk, &sb, sh.cbest, ia, c, gx, gy, ax, ay);
+      sh.rx2 = ax;
+      sh.ry2 = ay;
+      sh.sob2 = sb;
+      sh.pk_pos = pk.pos;
+      sh.pk_ok = pk.bad ? 0 : 1;
+      sh.plen = sh.cbest;   // c_best the read-ahead used
     }
+    if (tid == 64 && !(step + 1 < iters && it + 1 < c.max_iter)) sh.pk_ok = 0;
     __syncthreads();
     const double nx = sh.nx, ny = sh.ny;
     s_eu++;
@@ -349,7 +612,27 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       // ---------------- find_near_nodes :1137-1143  (n_node = len(node_list), radius not capped)
       const double r2 = c.r2tab[n];
       int kraw;
-      if (f32_ok && rpp::dabs(nx) <= fmax && rpp::dabs(ny) <= fmax) {
+      const bool n_in = nx >= q_glo && nx <= q_ghi && ny >= q_glo && ny <= q_ghi;
+      if (q16_ok && !n_in) q16_ok = 0;   // the new node cannot be represented on the grid: f32 / f64 passes from here on
+      if (q16_ok) {
+        // ONE pass answers the near-ball query of this iteration and -- when the next sample is known (read-ahead valid)
+        // and lies on the grid -- the nearest query of the next: superset ball {grid distance <= r + q_m}
+        const double rg = (__builtin_sqrt(r2) + c.q_m) * c.q_inv;
+        const double t2 = rg * rg * (1.0 + 1e-9) + 1.0;
+        const uint32_t thr = t2 >= 4294967295.0 ? 0xffffffffu : (uint32_t)t2;
+        const uint32_t qq = rppk::quant16(c, nx, ny);
+        const double ax = sh.rx2, ay = sh.ry2;
+        const bool pre = sh.pk_ok && ax >= q_glo && ax <= q_ghi && ay >= q_glo && ay <= q_ghi;
+        if (pre) {
+          kraw = scan_q16<true, true>(xq, n, qq, thr, rppk::quant16(c, ax, ay), hits, sh, p_grp, p_best, p_second);
+          have_n = 1;
+        } else {
+          int g0;
+          uint32_t b0, b1;
+          kraw = scan_q16<true, false>(xq, n, qq, thr, 0u, hits, sh, g0, b0, b1);
+        }
+        s_ab += 4 * (int64_t)n + 16 * (int64_t)kraw;
+      } else if (f32_ok && rpp::dabs(nx) <= fmax && rpp::dabs(ny) <= fmax) {
         const double rr = __builtin_sqrt(r2) + fm;   // ball radius r + m in the f32 metric, rounded up
         kraw = rppk::scan_hits_f32(xf, yf, n, (float)nx, (float)ny, (float)(rr * rr * (1.0 + 1e-6)), hits, sh);
         s_ab += 8 * (int64_t)n + 16 * (int64_t)kraw;
@@ -428,6 +711,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
             xf[n] = (float)nx;
             yf[n] = (float)ny;
           }
+          if (xq) xq[n] = rppk::quant16(c, nx, ny);
           cost[n] = ncost;
           parent[n] = sh.npar;
           sh.nrw = 0;
@@ -532,6 +816,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
           xf[n] = (float)nx;
           yf[n] = (float)ny;
         }
+        if (xq) xq[n] = rppk::quant16(c, nx, ny);
         cost[n] = ncost;
         parent[n] = sh.npar;
         sh.nrw = 0;
@@ -625,6 +910,32 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       c.tr_nn[it] = nnear;
     }
     if (sh.overflow) stop = 1;
+    // ---------------- commit the read-ahead: valid when the draw stayed inside the MT block and c_best is still the value it
+    // used (bitwise: c_best only ever changes to a smaller finite value)
+    const bool keep = sh.pk_ok && rpp::d2b(sh.plen) == rpp::d2b(sh.cbest) && !stop;
+    if (keep && have_n && accepted) {
+      // the node appended after the pass takes part in the prefetched nearest answer with its own grid distance
+      const uint32_t dn = qdist_i(rppk::quant16(c, nx, ny), rppk::quant16(c, sh.rx2, sh.ry2));
+      if (dn < p_best) {
+        p_second = p_best;
+        p_best = dn;
+        p_grp = NEWNODE;
+      } else if (dn < p_second) {
+        p_second = dn;
+      }
+    }
+    __syncthreads();
+    if (keep) {
+      if (tid == 0) {
+        sh.rx = sh.rx2;
+        sh.ry = sh.ry2;
+        sh.rng.pos = sh.pk_pos;
+        sh.sob = sh.sob2;
+      }
+      have_s = 1;
+    } else {
+      have_n = 0;
+    }
     __syncthreads();
   }
 
@@ -632,10 +943,12 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
   for (int i = tid; i < 624; i += TPB) I->rng.mt[i] = sh.rng.mt[i];
   if (tid == 0) {
     I->rng.pos = sh.rng.pos;
-    I->sobol = sob;
+    I->sobol = sh.sob;
     I->n = n;
     I->it = it;
     if (!f32_ok) I->first_goal = -3;
+    if (!q16_ok && c.xq) I->goal_dups = 1;
+    I->q16_fallbacks += s_qfb;
     PH_STORE(I);
     cbest_io[inst] = sh.cbest;
     if (it >= c.max_iter || sh.overflow) I->status |= 1;

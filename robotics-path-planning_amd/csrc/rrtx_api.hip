@@ -263,6 +263,8 @@ int rrtx_create(const rrtx_params* p, rrtx_handle** out) {
     if ((rc = dalloc(h, &c.elen, tot))) return rc;   // cached parent-edge lengths (cost propagation)
     if ((rc = dalloc(h, &c.xq, tot))) return rc;     // 16-bit mirror (first stage of the streaming pass)
   }
+  if (p->algo == RRTX_ALGO_INFORMED)
+    if ((rc = dalloc(h, &c.xq, tot))) return rc;     // 16-bit mirror: the one pass per iteration of the rrt_07 kernel
   if ((rc = dalloc(h, &c.results, h->n_inst))) return rc;
   c.path_cap = (int32_t)(cap + 1 < 8192 ? cap + 1 : 8192);
   if ((rc = dalloc(h, &c.path_xy, (size_t)h->n_inst * c.path_cap * 2))) return rc;
@@ -525,6 +527,16 @@ int rrtx_plan(rrtx_handle* h) {
         if (q < lo) lo = q;
         if (q > hi) hi = q;
       }
+    }
+    if (c.algo == RRTX_ALGO_INFORMED) {
+      // rrt_07's informed samples are not clipped to the sampling square (the ellipse of :1145-1159 may reach past it) and
+      // a node may step expand_dis beyond its sample: an eighth of the range on every side.  A node that still leaves the
+      // grid switches its instance to the f32 / f64 passes (rrt_informed.hip.h)
+      double frac = 0.125;
+      if (const char* e = getenv("RRTX_Q16_PAD")) frac = atof(e);   // test knob: a negative margin makes nodes leave the grid
+      const double pad = frac * (hi - lo > 1e-9 ? hi - lo : 1.0) + (frac >= 0.0 ? fabs(c.expand_dis) : 0.0);
+      lo -= pad;
+      hi += pad;
     }
     const double range = hi - lo > 1e-9 ? hi - lo : 1.0;
     c.q_lo = lo;

@@ -1293,3 +1293,127 @@ def test_batch_planner_sharded_over_handles_equals_one_handle(gpu, algo):
     finally:
         one.close()
         many.close()
+
+
+def _orc_bench_tree(a):
+    import oracle
+    w, kw, it, sd = a
+    if w == "c3":
+        kc = dict(kw)
+        kc.pop("algo")
+        kc["max_iter"] = it
+        r = oracle.plan_informed(seed=sd, exact_pow=False, **kc)
+        return r["x"], r["y"], r["cost"], r["parent"], r["path"], None
+    r = oracle.plan_dubins(kw["start"], kw["goal"], kw["obstacles"], kw["rand_area"], it, seed=sd)
+    return r["x"], r["y"], r["cost"], r["parent"], r["path"], r["yaw"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w", ["c3", "c5"])
+def test_gpu_bench_size_batches_sampled_against_oracle(gpu, w):
+    """The C3 (rrt_07, 1 024 x 20 000) and C5 (rrt_05, 1 536 x 5 000) batches exactly as bench.py builds and plans them
+    (its own Workload class: same map, constants, seeds, instance count, one handle), eight trees spread over the batch
+    against the oracle at the bench's size, bit for bit (round 2 held this in tools/ only)."""
+    import concurrent.futures as cf
+    import importlib
+    import types
+    import bench
+    import rrt_amd
+    sharding = importlib.import_module("robotics-path-planning_amd.sharding")
+    a = types.SimpleNamespace(workload=w, instances=None, max_iter=None, obstacles=None, warmup_max_iter=0)
+    wl = bench.Workload(a, np, util, rrt_amd)
+    wl.prepare(0, sharding)
+    assert (wl.B, wl.max_iter) == {"c3": (1024, 20000), "c5": (1536, 5000)}[w]
+    pick = sorted(set(int(v) for v in np.linspace(0, wl.B - 1, 8)))
+    with cf.ProcessPoolExecutor(max_workers=8) as ex:
+        fut = [ex.submit(_orc_bench_tree, (w, wl.kw, wl.max_iter, wl.seeds[i])) for i in pick]
+        h = wl.make_handle(wl.max_iter, 0)
+        try:
+            wl.step(h)
+            st = h.get_stats()
+            assert st["iterations"] == wl.B * wl.max_iter
+            for i, f in zip(pick, fut):
+                ox, oy, oc, op, opath, oyaw = f.result()
+                util.assert_tree_equal(h.get_tree(i), (ox, oy, oc, op), "%s instance %d" % (w, i))
+                path = h.get_path(i)
+                assert (path is None) == (opath is None)
+                if path is not None:
+                    assert np.array_equal(np.asarray(path)[:, :2], np.asarray(opath)[:, :2])
+                if oyaw is not None:
+                    assert np.array_equal(h.get_yaw(i), oyaw)
+            if w == "c3":
+                assert st["q16_fallbacks"] > 0      # the one-pass 16-bit first stage ran (and handed some queries down)
+        finally:
+            h.close()
+
+
+@pytest.mark.gpu
+def test_gpu_informed_near_set_overflow_is_replanned_on_the_large_shape(gpu):
+    """rrt_07's near radius 50*sqrt(ln n / n) is not capped (:1139): on a 5 x 5 area it covers the whole tree, so the near
+    set outgrows the 512 LDS candidate slots of the product shape after ~520 nodes.  rrtx_plan then plans the instance again
+    on the 2 048-slot instantiation (one workgroup per CU, ~124 KB of LDS; round-2 ADVICE: that path had no test): tree,
+    path and RNG state equal the oracle's, rrtx_stats.replanned counts it.  Beyond 2 048 candidates the instance ends with
+    RRTX_ST_OVERFLOW and the call returns RRTX_PARTIAL -- for that instance only: an instance whose start lies inside an
+    obstacle (every extension collides, the tree stays at its root) completes in the same batch."""
+    import oracle
+    import rrt_amd
+    A = rrt_amd._abi
+    obst = [(2.5, 2.5, 0.3), (1.0, 3.5, 0.25), (3.8, 1.2, 0.25)]
+    kw = dict(start=[0.5, 0.5], goal=[4.5, 4.5], obstacles=obst, rand_area=[0.0, 5.0], expand_dis=0.08,
+              goal_sample_rate=10, max_iter=1500, sobol=0)
+    seeds = [3, 4]
+    out = util.run_gpu_informed(kw, seeds)
+    assert out["stats"]["replanned"] == 2 and out["stats"]["near_unique"] > 512 * 500
+    for i, s in enumerate(seeds):
+        r = oracle.plan_informed(seed=s, **kw)
+        assert len(r["x"]) > 900
+        util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "seed %d" % s)
+        assert (out["paths"][i] is None) == (r["path"] is None)
+        if r["path"] is not None:
+            assert np.array_equal(out["paths"][i], r["path"]) and out["results"][0][i] == r["c_best"]
+        assert out["rng"][i][1][624] == r["rng"].pos and out["rng"][i][1][0] == r["rng"].mt[0]
+    # more than 2 048 candidates: per-instance overflow, the walled-in instance of the same batch completes
+    c_min, c = rrt_amd.informed_rotation(kw["start"], kw["goal"])
+    h = A.Handle(A.ALGO_INFORMED, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], 1.0, 10, 3200,
+                 n_instances=2, informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+    try:
+        h.set_obstacles(obst)
+        h.seed_instances([3, 4])
+        h.set_instance(1, [2.5, 2.5], [4.5, 4.5])
+        cm1, c1 = rrt_amd.informed_rotation([2.5, 2.5], [4.5, 4.5])
+        h.set_instance_rotation(1, [c1[0, 0], c1[0, 1], c1[1, 0], c1[1, 1]], cm1)
+        assert h.plan() == A.RRTX_PARTIAL and "RRTX_ST_OVERFLOW" in h.last_error()
+        pc, nn, st = h.get_results()
+        assert st[0] & A.ST_OVERFLOW and not (st[1] & A.ST_FAILED) and st[1] & A.ST_DONE
+        assert nn[1] == 1 and nn[0] > 2048
+    finally:
+        h.close()
+
+
+@pytest.mark.gpu
+def test_gpu_informed_nodes_leaving_the_16bit_grid_fall_back(gpu, monkeypatch):
+    """rrt_07 kernel: the one-pass 16-bit first stage holds while every node lies on the grid square (sampling square plus
+    a margin).  RRTX_Q16_PAD=-0.02 shrinks the square INTO the sampling area, so samples near the border are off the grid
+    (their nearest query takes the f32 pass) and the first node that steps off it switches the instance to the f32 / f64
+    passes for good; RRTX_Q16=0 never uses the grid.  All three give the oracle's trees."""
+    import oracle
+    g = util.load_golden(util.GOLDEN + "/rrt07_c3_sobol_s1_it3000.npz")
+    kw = util.informed_kwargs_from_golden(g)
+    kw["max_iter"] = 2500
+    kw["start"], kw["goal"] = [4.0, 4.0], [96.0, 96.0]      # inside the shrunk grid; the tree is free to walk to the border
+    kw["obstacles"] = [o for o in kw["obstacles"] if (o[0] - 4) ** 2 + (o[1] - 4) ** 2 > (o[2] + 1) ** 2
+                       and (o[0] - 96) ** 2 + (o[1] - 96) ** 2 > (o[2] + 1) ** 2]
+    seeds = list(range(21, 29))
+    ref = [oracle.plan_informed(seed=s, **kw) for s in seeds]
+    for env in ({}, {"RRTX_Q16_PAD": "-0.02"}, {"RRTX_Q16": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = util.run_gpu_informed(kw, seeds)
+        for k in env:
+            monkeypatch.delenv(k)
+        for i, s in enumerate(seeds):
+            r = ref[i]
+            util.assert_tree_equal(out["trees"][i], (r["x"], r["y"], r["cost"], r["parent"]), "%s seed %d" % (env, s))
+            assert (out["paths"][i] is None) == (r["path"] is None)
+        if env.get("RRTX_Q16") == "0":
+            assert out["stats"]["q16_fallbacks"] == 0
