@@ -38,7 +38,10 @@ struct ShIT {
   rpp::MT rng;
   double ox[MAX_OBS], oy[MAX_OBS], othr[MAX_OBS];
   double orad[MAX_OBS];   // obstacle radius (sqrt of the threshold), rounded up: the cheap reject test of choose_parent
-  int32_t uidx[NUI], ufree[NUI];
+  int32_t uidx[NUI];
+  int8_t ufree[NUI];        // -1 not tested, 0 blocked, 1 free
+  int16_t urank[NUI];       // choose_parent: rank of a candidate by (cost, list position)
+  int16_t tl[TPB];          // candidate slots whose segment is to be tested next (test_candidates)
   // uval (d**2 of a candidate, duplicate collapse) and cval (per-thread scratch of the same phase) are dead before
   // choose_parent writes ud / uex: they share storage, which keeps the block under 40 KB (4 workgroups per CU)
   union { double uval[NUI]; double ud[NUI]; };
@@ -52,6 +55,9 @@ struct ShIT {
   rpp::Sobol sob, sob2;     // Sobol state (any thread may draw), and the state after the peeked draw
   int32_t flag, nu, nvalid, overflow, ecoll, npar, nrw;
   int32_t pk_pos, pk_ok;    // MT19937 position after the peeked draw; 1 = the peek stayed inside the current 624-word block
+  int32_t ntl, near_goal, nrw2;
+  int16_t tlx[64];          // test_candidates: slots that need the exact (atan2 / cos / sin) form
+  double ct, st;            // steer: cos(theta) from wave 0, sin(theta) from wave 2
 };
 
 // numpy `u.dot(w)` for 2-vectors on the golden box: fma(u1, w1, u0*w0)
@@ -89,12 +95,13 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
   for (int base = 0; base < kraw; base += TPB) {
     const int h = base + tid;
     int idx = -1;
-    double v = 0.0, hx = 0.0, hy = 0.0;
+    double v = 0.0, hx = 0.0, hy = 0.0, hc = 0.0;
     bool valid = false;
     if (h < kraw) {
       idx = rppk::hit_at(hits, sh, h);
       hx = x[idx];
       hy = y[idx];
+      hc = cost[idx];   // requested with the coordinates (one round trip), used only if the hit becomes a candidate
       v = rpp::py_d2(hx - qx, hy - qy);
       valid = v <= thr_exact;
     }
@@ -134,7 +141,7 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
         sh.uidx[p] = idx;
         sh.ux[p] = hx;
         sh.uy[p] = hy;
-        sh.ucost[p] = cost[idx];
+        sh.ucost[p] = hc;
       }
     }
     __syncthreads();
@@ -149,35 +156,92 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
   }
 }
 
-// check_collision (rrt_07:1271-1276) of the candidate slots listed in sh.cflag[0..nt) (nt <= TPB): lane t derives
-// (theta, end point) of its candidate exactly as choose_parent :1117-1119 / rewire :1242-1244 do -- both arrive at the same
-// (theta, d) -- then a wave takes a candidate, its lanes the obstacles.  The exact segment distance (:1249-1261) is
-// evaluated only for obstacles that can touch the segment: dist(p, segment) >= |p - midpoint| - half length, so
-// |p - mid| > half length + radius (with 1e-9 of slack against the roundings of this test) leaves
-// `distance**2 <= size**2` false whatever the exact form returns.  Result in sh.ufree[e] (1 free, 0 blocked).
+// check_collision (rrt_07:1271-1276) of the candidate slots listed in sh.tl[0..nt) (nt <= TPB); result in sh.ufree[e]
+// (1 free, 0 blocked).  The reference tests the segment from the candidate v to end = v + (cos theta, sin theta) * d with
+// theta = atan2(new - v), d = hypot(new - v) (:1117-1119 / :1242-1244 arrive at the same (theta, d)): `end` is the new
+// node up to the roundings of those four calls (a few ULP of the coordinates).  A wave takes a candidate, its lanes the
+// obstacles, and evaluates the segment distance (:1249-1261) with the NEW NODE ITSELF as the end point:
+//   * obstacles out of reach of the segment are dropped first: dist(p, segment) >= |p - midpoint| - half length;
+//   * a distance**2 that clears `size**2` by more than `tol` on either side decides the comparison (:1267) for that obstacle
+//     whatever the few-ULP difference of the end point and the roundings of the formula do (tol is ~1e4 times their bound);
+//   * an obstacle inside the band sends the candidate to the exact form: atan2 / cos / sin replicas, cosine on a lane of
+//     wave 0 and sine on a lane of wave 1, then the reference's expression -- a few times per 10^6 tests.
+// So a verdict costs no libm-grade call in all but those cases (before: three calls deep per batch, lanes diverging).
 template <int NUI>
-__device__ __forceinline__ void test_candidates(const Ctx& c, ShIT<NUI>& sh, int nt, double nx, double ny) {
+__device__ __forceinline__ void test_candidates(const Ctx& c, ShIT<NUI>& sh, int nt, double nx, double ny, double tolmul) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid < nt) {
-    const int e = sh.cflag[tid];
-    const double dx = nx - sh.ux[e], dy = ny - sh.uy[e];
-    const double th = rpp_glibc_atan2(dy, dx);
-    const double d = sh.ud[e];
-    sh.uex[e] = sh.ux[e] + rpp_glibc_cos(th) * d;
-    sh.uey[e] = sh.uy[e] + rpp_glibc_sin(th) * d;
-  }
+  if (tid == 0) sh.nrw2 = 0;   // candidates that need the exact form
   __syncthreads();
   for (int t = w; t < nt; t += NW) {
-    const int e = sh.cflag[t];
-    const double vx = sh.ux[e], vy = sh.uy[e], ex2 = sh.uex[e], ey2 = sh.uey[e];
-    const double mx = 0.5 * (vx + ex2), my = 0.5 * (vy + ey2), hl = 0.5 * sh.ud[e] * (1.0 + 1e-12);
-    bool hit = false;
+    const int e = sh.tl[t];
+    const double vx = sh.ux[e], vy = sh.uy[e], d = sh.ud[e];
+    const double mx = 0.5 * (vx + nx), my = 0.5 * (vy + ny), hl = 0.5 * d * (1.0 + 1e-9) + 1e-9;
+    const double sc = 1.0 + rpp::dabs(vx) + rpp::dabs(vy) + rpp::dabs(nx) + rpp::dabs(ny);
+    bool hit = false, unsure = false;
     for (int k = lane; k < c.m; k += 64) {
       const double ddx = sh.ox[k] - mx, ddy = sh.oy[k] - my, tt = hl + sh.orad[k];
       if (ddx * ddx + ddy * ddy <= tt * tt * (1.0 + 1e-9)) {
-        if (seg_dist2(vx, vy, ex2, ey2, sh.ox[k], sh.oy[k]) <= sh.othr[k]) hit = true;
+        const double a = seg_dist2(vx, vy, nx, ny, sh.ox[k], sh.oy[k]);
+        const double tol = 1e-10 * sc * (1.0 + d + sh.orad[k]) * tolmul;   // tolmul = 1; a test knob makes every verdict take the exact form
+        if (a <= sh.othr[k] - tol)
+          hit = true;
+        else if (a <= sh.othr[k] + tol)
+          unsure = true;
       }
     }
+    const bool any = __ballot(hit) != 0ull, uns = __ballot(unsure) != 0ull;
+    if (lane == 0) {
+      sh.ufree[e] = any ? 0 : 1;
+      if (!any && uns) sh.tlx[atomicAdd(&sh.nrw2, 1) & 63] = (int16_t)e;
+    }
+  }
+  __syncthreads();
+  const int nx2 = sh.nrw2;
+  if (nx2 == 0) return;
+  // exact form for the candidates left undecided (at most 64 per round trip: more cannot occur with nt <= 256 in practice,
+  // and if they did the list wraps and the overwritten ones are found again by the caller's next test of an untested slot --
+  // they keep ufree = 1 only if listed, so mark every undecided slot untested first)
+  __syncthreads();
+  if (nx2 > 64) {   // never observed; fall back to the exact form for the whole list
+    for (int t0 = 0; t0 < nt; t0 += 64) {
+      const int t = t0 + lane;
+      if (w < 2 && t < nt) {
+        const int e = sh.tl[t];
+        const double th = rpp_glibc_atan2(ny - sh.uy[e], nx - sh.ux[e]);
+        if (w == 0)
+          sh.uex[e] = sh.ux[e] + rpp_glibc_cos(th) * sh.ud[e];
+        else
+          sh.uey[e] = sh.uy[e] + rpp_glibc_sin(th) * sh.ud[e];
+      }
+    }
+    __syncthreads();
+    for (int t = w; t < nt; t += NW) {
+      const int e = sh.tl[t];
+      const double vx = sh.ux[e], vy = sh.uy[e], ex2 = sh.uex[e], ey2 = sh.uey[e];
+      bool hit = false;
+      for (int k = lane; k < c.m; k += 64)
+        if (seg_dist2(vx, vy, ex2, ey2, sh.ox[k], sh.oy[k]) <= sh.othr[k]) hit = true;
+      const bool any = __ballot(hit) != 0ull;
+      if (lane == 0) sh.ufree[e] = any ? 0 : 1;
+    }
+    __syncthreads();
+    return;
+  }
+  if (w < 2 && lane < nx2) {
+    const int e = sh.tlx[lane];
+    const double th = rpp_glibc_atan2(ny - sh.uy[e], nx - sh.ux[e]);
+    if (w == 0)
+      sh.uex[e] = sh.ux[e] + rpp_glibc_cos(th) * sh.ud[e];
+    else
+      sh.uey[e] = sh.uy[e] + rpp_glibc_sin(th) * sh.ud[e];
+  }
+  __syncthreads();
+  for (int t = w; t < nx2; t += NW) {
+    const int e = sh.tlx[t];
+    const double vx = sh.ux[e], vy = sh.uy[e], ex2 = sh.uex[e], ey2 = sh.uey[e];
+    bool hit = false;
+    for (int k = lane; k < c.m; k += 64)
+      if (seg_dist2(vx, vy, ex2, ey2, sh.ox[k], sh.oy[k]) <= sh.othr[k]) hit = true;
     const bool any = __ballot(hit) != 0ull;
     if (lane == 0) sh.ufree[e] = any ? 0 : 1;
   }
@@ -269,7 +333,13 @@ __device__ __forceinline__ void informed_sample(R* rng, rpp::Sobol* sob, double 
 // Both are SUPERSET / candidate answers: the callers decide on the f64 coordinates.
 typedef uint32_t v4u_i __attribute__((ext_vector_type(4)));
 typedef short s2v_i __attribute__((ext_vector_type(2)));
-constexpr int QDI = 4;
+#ifndef RRTX_QDI
+#define RRTX_QDI 4
+#endif
+#ifndef RRTX_QNT
+#define RRTX_QNT 0
+#endif
+constexpr int QDI = RRTX_QDI;
 constexpr int QSLOT_I = 256;
 constexpr uint32_t QSAT_I = 32767u * 32767u;
 constexpr int NEWNODE = -2;   // "group" of a nearest answer that is the node appended after the pass
@@ -322,6 +392,13 @@ __device__ __forceinline__ void scan_q16_slot(const v4u_i v, const int i0, const
   }
 }
 
+__device__ __forceinline__ v4u_i qload(const v4u_i* p) {
+#if RRTX_QNT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 template <bool NEAR, bool NEAREST, class SH>
 __device__ __forceinline__ int scan_q16(const uint32_t* __restrict__ xq, int n, uint32_t qq, uint32_t thr, uint32_t sq,
                                         int32_t* __restrict__ hits, SH& sh, int& ggrp, uint32_t& gbest, uint32_t& gsecond) {
@@ -341,7 +418,7 @@ __device__ __forceinline__ int scan_q16(const uint32_t* __restrict__ xq, int n, 
     const int rounds = (nsl + QDI - 1) / QDI;
     v4u_i q[QDI];
 #pragma unroll
-    for (int u = 0; u < QDI; u++) q[u] = __builtin_nontemporal_load(pv + 64 * (u < last ? u : last));
+    for (int u = 0; u < QDI; u++) q[u] = qload(pv + 64 * (u < last ? u : last));
     int s0 = 0;
     for (int r = 0; r + 1 < rounds; r++, s0 += QDI) {
 #pragma unroll
@@ -350,7 +427,7 @@ __device__ __forceinline__ int scan_q16(const uint32_t* __restrict__ xq, int n, 
         scan_q16_slot<NEAR, NEAREST, false>(q[u], ws + sl * QSLOT_I + lane * 4, n, qq, thr, sq, lt_mask, hits, ws, cnt, best,
                                             second, bgrp);
         const int nx = sl + QDI;
-        q[u] = __builtin_nontemporal_load(pv + 64 * (nx < last ? nx : last));   // unconditional, clamped to the last slot
+        q[u] = qload(pv + 64 * (nx < last ? nx : last));   // unconditional, clamped to the last slot
       }
     }
 #pragma unroll
@@ -399,6 +476,8 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
   const int tid = threadIdx.x;
   Inst* I = c.inst + inst;
   if (I->status & 1) return;
+  const double tolmul = (eager & 2) ? 1e30 : 1.0;   // RRTX_INFORMED_EXACT_SEG=1: every near obstacle goes through the exact segment form
+  eager &= 1;
   const int64_t off = (int64_t)inst * c.stride;
   double* __restrict__ x = c.x + off;
   double* __restrict__ y = c.y + off;
@@ -566,21 +645,16 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
 
     PH(1);
     // ---------------- steer :1080-1083 / get_new_node :1216-1224, extension edge :1085
+    // lane 0: atan2 -> cos; lane 0 of wave 2: the same atan2 -> sin (the replicas are pure functions: both lanes hold the
+    // same theta); lane 0 of wave 1: the read-ahead draw.  Then lane 0 finishes the node, lane 0 of wave 3 the goal test.
+    const double r2n = c.r2tab[n];   // near radius of this iteration (:1139), requested here, used after the steer
+    const double qx = x[ni], qy = y[ni];
     if (tid == 0) {
-      const double qx = x[ni], qy = y[ni];
       const double theta = rpp_glibc_atan2(ry - qy, rx - qx);
-      const double ct = rpp_glibc_cos(theta), st = rpp_glibc_sin(theta);
-      const double nx = qx + E * ct, ny = qy + E * st;
-      const double d = rpp::py_hypot(qx - nx, qy - ny);        // line_cost :1206
-      sh.nx = nx;
-      sh.ny = ny;
-      sh.ux[0] = qx;                                            // segment start (candidate slot 0 is free here)
-      sh.uy[0] = qy;
-      sh.ex = qx + ct * d;                                      // check_collision :1273-1274
-      sh.ey = qy + st * d;
-      sh.ncost = cost[ni] + E;                                  // :1222
-      sh.npar = ni;
-      sh.ecoll = 0;
+      sh.ct = rpp_glibc_cos(theta);
+    } else if (tid == 128) {
+      const double theta = rpp_glibc_atan2(ry - qy, rx - qx);
+      sh.st = rpp_glibc_sin(theta);
     } else if (tid == 64 && step + 1 < iters && it + 1 < c.max_iter) {
       // the sample of iteration it+1, read ahead on another wave while lane 0 steers: it depends on the RNG / Sobol state
       // and on c_best only.  Nothing is consumed here; the draw is committed at the end of this iteration if c_best is
@@ -598,6 +672,25 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
     }
     if (tid == 64 && !(step + 1 < iters && it + 1 < c.max_iter)) sh.pk_ok = 0;
     __syncthreads();
+    {
+      const double ct = sh.ct, st = sh.st;
+      const double nx0 = qx + E * ct, ny0 = qy + E * st;         // get_new_node :1219-1220
+      if (tid == 0) {
+        const double d = rpp::py_hypot(qx - nx0, qy - ny0);      // line_cost :1206
+        sh.nx = nx0;
+        sh.ny = ny0;
+        sh.ux[0] = qx;                                            // segment start (candidate slot 0 is free here)
+        sh.uy[0] = qy;
+        sh.ex = qx + ct * d;                                      // check_collision :1273-1274
+        sh.ey = qy + st * d;
+        sh.ncost = cost[ni] + E;                                  // :1222
+        sh.npar = ni;
+        sh.ecoll = 0;
+      } else if (tid == 192) {
+        sh.near_goal = (rpp::py_hypot(nx0 - gx, ny0 - gy) < E) ? 1 : 0;   // is_near_goal :1226-1230 (strict), used by :1094
+      }
+    }
+    __syncthreads();
     const double nx = sh.nx, ny = sh.ny;
     s_eu++;
     s_er++;
@@ -610,7 +703,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
     if (accepted) {
       PH(2);
       // ---------------- find_near_nodes :1137-1143  (n_node = len(node_list), radius not capped)
-      const double r2 = c.r2tab[n];
+      const double r2 = r2n;
       int kraw;
       const bool n_in = nx >= q_glo && nx <= q_ghi && ny >= q_glo && ny <= q_ghi;
       if (q16_ok && !n_in) q16_ok = 0;   // the new node cannot be represented on the grid: f32 / f64 passes from here on
@@ -641,6 +734,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         s_ab += 16 * (int64_t)n;
       }
       s_sn += n;
+      PH(3);
       build_candidates_i(x, y, cost, nx, ny, r2, hits, kraw, sh);
       const int nu = sh.nu, nvalid = sh.nvalid;
       nnear = nu;
@@ -659,30 +753,53 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
           sh.ud[e] = rpp::py_hypot(nx - sh.ux[e], ny - sh.uy[e]);
           sh.ufree[e] = -1;
         }
+        if (tid == 0) {
+          sh.ntl = 0;
+          sh.flag = 0x7fffffff;
+        }
         __syncthreads();
+        // rank + the first batch: the 4 cheapest candidates, and with them the candidates rewire (:1232-1246) will most
+        // likely ask for -- those whose cost would improve if the cheapest candidate becomes the parent (the usual case).
+        // That guess only decides WHEN a segment is tested: rewire below still tests whatever it needs and has no verdict for
+        constexpr int B0 = 4;
         for (int e = tid; e < nu; e += TPB) {
           const double ce = sh.ucost[e] + sh.ud[e];
           int rk = 0;
+          double cmin = rpp::dinf();
 #pragma unroll 4
           for (int j = 0; j < nu; j++) {
             const double cj = sh.ucost[j] + sh.ud[j];
             rk += (cj < ce || (cj == ce && j < e)) ? 1 : 0;
+            cmin = cj < cmin ? cj : cmin;
           }
-          sh.uey[e] = (double)rk;
+          sh.urank[e] = (int16_t)rk;
+          if (rk < B0) sh.cflag[rk] = e;
+          if (rk < B0 || (nu <= TPB && sh.ucost[e] > cmin + sh.ud[e])) sh.tl[atomicAdd(&sh.ntl, 1)] = (int16_t)e;   // <= max(B0, nu) entries
         }
         __syncthreads();
+        PH(5);
         int tested = 0, found = 0;
-        for (int base = 0, bsz = 4; base < nu && !found; base += bsz, bsz = bsz < TPB / 2 ? 2 * bsz : TPB) {
+        for (int base = 0, bsz = B0; base < nu && !found; base += bsz, bsz = bsz < TPB / 2 ? 2 * bsz : TPB) {
           const int na = (nu - base < bsz) ? nu - base : bsz;
-          if (tid == 0) sh.flag = 0x7fffffff;
-          for (int e = tid; e < nu; e += TPB) {
-            if (sh.ufree[e] >= 0) continue;   // tested in an earlier batch (its uey[] is an end point now)
-            const int rk = (int)sh.uey[e];
-            if (rk >= base && rk < base + na) sh.cflag[rk - base] = e;
+          if (base > 0) {
+            // a later batch (the whole first one was blocked): ranks base .. base + na - 1, minus what has a verdict already
+            if (tid == 0) {
+              sh.ntl = 0;
+              sh.flag = 0x7fffffff;
+            }
+            __syncthreads();
+            for (int e = tid; e < nu; e += TPB) {
+              const int rk = sh.urank[e];
+              if (rk >= base && rk < base + na) {
+                sh.cflag[rk - base] = e;
+                if (sh.ufree[e] < 0) sh.tl[atomicAdd(&sh.ntl, 1)] = (int16_t)e;
+              }
+            }
+            __syncthreads();
           }
-          __syncthreads();
-          test_candidates(c, sh, na, nx, ny);   // overwrites uey[] of the tested slots only: their rank is in cflag order
-          tested += na;
+          const int nt = sh.ntl;
+          test_candidates(c, sh, nt, nx, ny, tolmul);
+          tested += nt;
           if (tid < na && sh.ufree[sh.cflag[tid]] == 1) atomicMin(&sh.flag, tid);
           __syncthreads();
           const int t = sh.flag;
@@ -703,7 +820,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         PH(6);
         // ---------------- append :1091, rewire :1232-1246: only a candidate with `near_node.cost > s_cost` (:1241) gets a
         // collision test (:1244); nothing the loop writes is read by a later candidate (no propagation in rrt_07), so
-        // the candidates are independent.  Those not tested by choose_parent are tested now.
+        // the candidates are independent.  Those without a verdict yet are tested now.
         if (tid == 0) {
           x[n] = nx;
           y[n] = ny;
@@ -715,21 +832,21 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
           cost[n] = ncost;
           parent[n] = sh.npar;
           sh.nrw = 0;
-          sh.flag = 0;
+          sh.ntl = 0;
         }
         __syncthreads();
         int extra = 0;
         for (int e0 = 0; e0 < nu; e0 += TPB) {
           const int e = e0 + tid;
           const bool need = e < nu && sh.ucost[e] > ncost + sh.ud[e] && sh.ufree[e] < 0;
-          if (need) sh.cflag[atomicAdd(&sh.flag, 1)] = e;
+          if (need) sh.tl[atomicAdd(&sh.ntl, 1)] = (int16_t)e;
           __syncthreads();
-          const int nt = sh.flag;
+          const int nt = sh.ntl;
           __syncthreads();
           if (nt > 0) {
-            test_candidates(c, sh, nt, nx, ny);
+            test_candidates(c, sh, nt, nx, ny, tolmul);
             extra += nt;
-            if (tid == 0) sh.flag = 0;
+            if (tid == 0) sh.ntl = 0;
             __syncthreads();
           }
         }
@@ -845,12 +962,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       PH(9);
       }   // eager
       // ---------------- goal bookkeeping :1094-1103
-      if (tid == 0) {
-        sh.flag = (rpp::py_hypot(nx - gx, ny - gy) < E) ? 1 : 0;   // is_near_goal :1226-1230 (strict)
-        sh.ecoll = 0;
-      }
-      __syncthreads();
-      if (sh.flag) {
+      if (sh.near_goal) {   // is_near_goal :1226-1230, evaluated beside the steer (sh.ecoll is 0 here: the node was accepted)
         s_eu++;
         s_er++;
         for (int k = tid; k < c.m; k += TPB)

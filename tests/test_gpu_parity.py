@@ -371,6 +371,13 @@ def test_gpu_informed_candidate_order_does_not_change_the_tree(gpu, monkeypatch)
             assert (lazy["paths"][i] is None) == (r["path"] is None)
             if r["path"] is not None:
                 assert np.array_equal(lazy["paths"][i], r["path"]) and lazy["results"][0][i] == r["c_best"]
+        # collision verdicts from the exact (atan2 / cos / sin end point) form for every near obstacle instead of the
+        # tolerance band around the new node: same trees (the band only decides which form is evaluated)
+        monkeypatch.setenv("RRTX_INFORMED_EXACT_SEG", "1")
+        exact = util.run_gpu_informed(k, seeds)
+        monkeypatch.delenv("RRTX_INFORMED_EXACT_SEG")
+        for i, s in enumerate(seeds):
+            util.assert_tree_equal(exact["trees"][i], lazy["trees"][i], "%s exact segment form, seed %d" % (name, s))
         # the reference-equivalent count is the same, the device tests several times fewer segments
         assert lazy["stats"]["edges_ref"] == eager["stats"]["edges_ref"]
         assert lazy["stats"]["edges_unique"] * 2 < eager["stats"]["edges_unique"]

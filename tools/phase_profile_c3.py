@@ -22,11 +22,12 @@ h.seed_instances(list(range(1, B + 1)))
 h.plan()
 s = h.get_stats()
 ph = h.get_phase_cycles()
-names = {0: "sample", 1: "nearest pass (+exact)", 2: "steer + extension collision", 4: "near pass + candidates",
-         6: "choose_parent", 9: "append + rewire", 15: "goal bookkeeping + loop"}
+names = {0: "sample (when not read ahead)", 1: "nearest (prefetched answer / own pass / 2nd pass)", 2: "steer + extension collision (+ read-ahead draw)",
+         3: "fused 16-bit pass (near + next nearest)", 4: "candidates: exact re-check + de-dup", 5: "choose_parent: hypot + rank",
+         6: "choose_parent: collision batches", 9: "append + rewire", 15: "goal bookkeeping + commit + loop"}
 tot = float(ph.sum())
 print("instances", B, "max_iter", it, "kernel_ms", s["kernel_ms"])
 for k in sorted(names):
     print("  %-30s %6.2f%%  %.1f cycles/iter/inst" % (names[k], 100.0 * ph[k] / tot if tot else 0, ph[k] / max(s["iterations"], 1)))
 print("  total cycles/iter/inst %.1f" % (tot / max(s["iterations"], 1)))
-print({k: s[k] for k in ("iterations", "edges_unique", "near_unique", "near_hits", "rewires")})
+print({k: s[k] for k in ("iterations", "edges_unique", "near_unique", "near_hits", "rewires", "q16_fallbacks", "exact_rescans")})
