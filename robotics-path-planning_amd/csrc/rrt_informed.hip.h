@@ -156,6 +156,85 @@ __device__ __forceinline__ void build_candidates_i(const double* __restrict__ x,
   }
 }
 
+// The same candidate records WITHOUT the two libm pow calls per hit, for the usual case in which no decision is close:
+// vf = dx*dx + dy*dy (correctly rounded squares) is within 2^-51 relative of the reference's dx**2 + dy**2, so a hit whose
+// vf is not within 2^-45 r**2 of r**2 has its `<= r**2` decided, and two hits whose vf differ by more than 2^-45 r**2 cannot
+// hold the same reference value (the `.index` collapse of :1140-1142 needs equal values).  Returns false -- nothing usable
+// written -- when some hit sits in the band or two hits are that close (exact duplicates included): the caller then runs
+// build_candidates_i.  Otherwise the candidates are the valid hits in list order.
+template <int NUI>
+__device__ __forceinline__ bool build_candidates_fast(const double* __restrict__ x, const double* __restrict__ y,
+                                                      const double* __restrict__ cost, double qx, double qy, double r2,
+                                                      const int32_t* hits, int kraw, ShIT<NUI>& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const double tol = r2 * 2.8421709430404007e-14;   // 2^-45 r**2
+  if (tid == 0) {
+    sh.nu = 0;
+    sh.nvalid = 0;
+    sh.nrw2 = 0;   // "a decision is close"
+  }
+  __syncthreads();
+  for (int base = 0; base < kraw; base += TPB) {
+    const int h = base + tid;
+    int idx = -1;
+    double v = rpp::b2d(0x7ff8000000000000ULL), hx = 0.0, hy = 0.0, hc = 0.0;
+    bool valid = false, unsure = false;
+    if (h < kraw) {
+      idx = rppk::hit_at(hits, sh, h);
+      hx = x[idx];
+      hy = y[idx];
+      hc = cost[idx];
+      v = rpp::fast_d2(hx - qx, hy - qy);
+      valid = v <= r2;
+      unsure = rpp::dabs(v - r2) <= tol;
+    }
+    const int nu = sh.nu;
+#pragma unroll 4
+    for (int u = 0; u < nu; u++) unsure |= rpp::dabs(sh.uval[u] - v) <= tol;       // NaN (no hit): never close
+    sh.cval[tid] = valid ? v : rpp::b2d(0x7ff8000000000000ULL);
+    __syncthreads();
+    const int nchunk = (kraw - base) < TPB ? (kraw - base) : TPB;
+    if (valid) {
+#pragma unroll 4
+      for (int t = 0; t < nchunk; t++) unsure |= (t != tid) & (rpp::dabs(sh.cval[t] - v) <= tol);
+    }
+    const uint64_t mv = __ballot(valid);
+    if (__ballot(unsure) != 0ull && lane == 0) sh.nrw2 = 1;
+    if (lane == 0) sh.red_idx[w] = __popcll(mv);
+    __syncthreads();
+    if (sh.nrw2) return false;   // uniform: written before the barrier
+    int off = nu;
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+      if (k < w) off += sh.red_idx[k];
+    int tot = nu;
+#pragma unroll
+    for (int k = 0; k < NW; k++) tot += sh.red_idx[k];
+    if (valid) {
+      const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      const int p = off + __popcll(mv & lt_mask);
+      if (p < NUI) {
+        sh.uval[p] = v;
+        sh.uidx[p] = idx;
+        sh.ux[p] = hx;
+        sh.uy[p] = hy;
+        sh.ucost[p] = hc;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      if (tot > NUI) {
+        sh.overflow = 1;
+        tot = NUI;
+      }
+      sh.nu = tot;
+      sh.nvalid = tot;
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
 // check_collision (rrt_07:1271-1276) of the candidate slots listed in sh.tl[0..nt) (nt <= TPB); result in sh.ufree[e]
 // (1 free, 0 blocked).  The reference tests the segment from the candidate v to end = v + (cos theta, sin theta) * d with
 // theta = atan2(new - v), d = hypot(new - v) (:1117-1119 / :1242-1244 arrive at the same (theta, d)): `end` is the new
@@ -328,8 +407,8 @@ __device__ __forceinline__ void informed_sample(R* rng, rpp::Sobol* sob, double 
 // (saturating 16-bit subtract + v_dot2_i32_i16).
 //   NEAR:    indices with grid distance**2 <= thr about the packed point qq, appended in ascending order to hits[]
 //            (wave w owns the slots starting at its range start; sh.wave_cnt / wave_start describe the segments);
-//   NEAREST: smallest and second smallest grid distance**2 to the packed point sq and the 4-node group (one load) the
-//            smallest came from; lowest group on ties.
+//   NEAREST: smallest and second smallest grid distance**2 to the packed point sq and the node the smallest came from;
+//            lowest index on ties.
 // Both are SUPERSET / candidate answers: the callers decide on the f64 coordinates.
 typedef uint32_t v4u_i __attribute__((ext_vector_type(4)));
 typedef short s2v_i __attribute__((ext_vector_type(2)));
@@ -366,7 +445,9 @@ __device__ __forceinline__ void scan_q16_slot(const v4u_i v, const int i0, const
     best = umin3_i(best, d[0], d[1]);
     second = min(second, umed3_i(best, d[2], d[3]));
     best = umin3_i(best, d[2], d[3]);
-    bgrp = best < b0 ? i0 : bgrp;
+    // the node itself (lowest of the group on ties), so that the caller needs no second look at the group
+    const int j = d[0] == best ? 0 : d[1] == best ? 1 : d[2] == best ? 2 : 3;
+    bgrp = best < b0 ? i0 + j : bgrp;
   }
   if (NEAR) {
     bool hh[4];
@@ -458,15 +539,6 @@ __device__ __forceinline__ int scan_q16(const uint32_t* __restrict__ xq, int n, 
   return total;
 }
 
-// the node of the group [grp, grp + 4) whose grid distance to `sq` is `best` (lowest index); -1 when none matches
-__device__ __forceinline__ int resolve_group_i(const uint32_t* __restrict__ xq, int grp, int n, uint32_t sq, uint32_t best) {
-  int r = -1;
-#pragma unroll
-  for (int j = 3; j >= 0; j--)
-    if (grp + j < n && qdist_i(xq[grp + j], sq) == best) r = grp + j;
-  return r;
-}
-
 template <int NUI, int WPS>
 __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const InformedArgs* __restrict__ per_inst,
                                                                 double* cbest_io, int iters, int eager) {
@@ -476,8 +548,9 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
   const int tid = threadIdx.x;
   Inst* I = c.inst + inst;
   if (I->status & 1) return;
-  const double tolmul = (eager & 2) ? 1e30 : 1.0;   // RRTX_INFORMED_EXACT_SEG=1: every near obstacle goes through the exact segment form
-  eager &= 1;
+  // test knobs (RRTX_INFORMED_EXACT_SEG=1): bit 1 = every near obstacle goes through the exact segment form, bit 2 = every
+  // candidate list through the exact `**2` form
+  const double tolmul = (eager & 2) ? 1e30 : 1.0;
   const int64_t off = (int64_t)inst * c.stride;
   double* __restrict__ x = c.x + off;
   double* __restrict__ y = c.y + off;
@@ -520,7 +593,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
   const double E = c.expand_dis;
   // Read-ahead across iterations (never across launches): have_s = this iteration's sample was drawn during the previous
   // one, have_n = its nearest query was answered by the previous iteration's pass: (p_best, p_second) grid distances,
-  // p_grp the 4-node group of the best (NEWNODE: the node appended after that pass)
+  // p_grp the node that holds the best (NEWNODE: the node appended after that pass)
   int have_s = 0, have_n = 0, p_grp = 0;
   uint32_t p_best = 0u, p_second = 0u;
   int64_t s_qfb = 0;
@@ -573,8 +646,8 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         // decision is taken on the f64 coordinates with the reference's own expression (first minimum, :1212-1213)
         const double rb = __builtin_sqrt((double)qb);
         if (__builtin_sqrt((double)qs) - rb > QMARGIN) {
-          ni = (qg == NEWNODE) ? n - 1 : resolve_group_i(xq, qg, n, sq, qb);
-          nearest_done = ni >= 0;
+          ni = (qg == NEWNODE) ? n - 1 : qg;
+          nearest_done = ni >= 0 && ni < n;
         }
         if (!nearest_done) {
           s_qfb++;
@@ -735,7 +808,11 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       }
       s_sn += n;
       PH(3);
-      build_candidates_i(x, y, cost, nx, ny, r2, hits, kraw, sh);
+      if ((eager & 4) || !build_candidates_fast(x, y, cost, nx, ny, r2, hits, kraw, sh)) {
+        __syncthreads();
+        build_candidates_i(x, y, cost, nx, ny, r2, hits, kraw, sh);
+        s_ex++;
+      }
       const int nu = sh.nu, nvalid = sh.nvalid;
       nnear = nu;
       s_nh += nvalid;
@@ -743,14 +820,16 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       s_ab += 48 * (int64_t)nu + 28;
       s_ab2 += 16 * (int64_t)n + 48 * (int64_t)nu + 28;
       PH(4);
-      if (!eager) {
+      if (!(eager & 1)) {
         // ---------------- choose_parent :1110-1135, cheapest first.  A candidate's cost `cost_i + d` (:1120) does not
         // depend on its collision test, so the candidates are ranked by (cost, list position) and tested in growing
         // batches (4, 8, 16 ...): the first free one in rank order IS the reference's `min(d_list)` / `.index` pick
         // (:1125-1126); later ones are never tested.  atan2 / cos / sin (:1118, :1273-1274) are evaluated for tested
         // candidates only.  ufree: -1 not tested, 0 blocked, 1 free.  The rank lives in uey[] until the slot is tested.
         for (int e = tid; e < nu; e += TPB) {
-          sh.ud[e] = rpp::py_hypot(nx - sh.ux[e], ny - sh.uy[e]);
+          const double de = rpp::py_hypot(nx - sh.ux[e], ny - sh.uy[e]);
+          sh.ud[e] = de;
+          sh.uex[e] = sh.ucost[e] + de;   // the candidate's cost :1120 (uex is free until a segment needs its exact form)
           sh.ufree[e] = -1;
         }
         if (tid == 0) {
@@ -763,12 +842,12 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         // That guess only decides WHEN a segment is tested: rewire below still tests whatever it needs and has no verdict for
         constexpr int B0 = 4;
         for (int e = tid; e < nu; e += TPB) {
-          const double ce = sh.ucost[e] + sh.ud[e];
+          const double ce = sh.uex[e];
           int rk = 0;
           double cmin = rpp::dinf();
 #pragma unroll 4
           for (int j = 0; j < nu; j++) {
-            const double cj = sh.ucost[j] + sh.ud[j];
+            const double cj = sh.uex[j];
             rk += (cj < ce || (cj == ce && j < e)) ? 1 : 0;
             cmin = cj < cmin ? cj : cmin;
           }

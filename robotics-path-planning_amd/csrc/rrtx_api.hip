@@ -637,8 +637,8 @@ int rrtx_plan(rrtx_handle* h) {
   }
   if (const char* e = getenv("RRTX_RS_EAGER")) h->da.eager = atoi(e) != 0;
   if (const char* e = getenv("RRTX_INFORMED_EAGER")) h->informed_eager = atoi(e) != 0;   // rrt_07: test every near candidate like the reference
-  if (const char* e = getenv("RRTX_INFORMED_EXACT_SEG"))   // rrt_07 test knob: no tolerance band, every verdict from the exact segment form
-    h->informed_eager = (h->informed_eager & 1) | (atoi(e) != 0 ? 2 : 0);
+  if (const char* e = getenv("RRTX_INFORMED_EXACT_SEG"))   // rrt_07 test knob: no tolerance bands -- every verdict from the exact segment form, every candidate list from the exact **2 form
+    h->informed_eager = (h->informed_eager & 1) | (atoi(e) != 0 ? 6 : 0);
   h->da.lazy = 0;
   h->da.filter = 1;
   if (const char* e = getenv("RRTX_DUBINS_FILTER")) h->da.filter = atoi(e) != 0;
