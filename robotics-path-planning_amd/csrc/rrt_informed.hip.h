@@ -60,6 +60,14 @@ struct ShIT {
   double ct, st;            // steer: cos(theta) from wave 0, sin(theta) from wave 2
 };
 
+// value of `v` in lane l of this wave (l wave-uniform); no LDS round trip: the all-pairs loops below walk a wave's registers
+__device__ __forceinline__ double readlane_d(double v, int l) {
+  const uint64_t b = __builtin_bit_cast(uint64_t, v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(b >> 32), l);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
 // numpy `u.dot(w)` for 2-vectors on the golden box: fma(u1, w1, u0*w0)
 __device__ __forceinline__ double np_dot2(double u0, double u1, double w0, double w1) {
   return __builtin_fma(u1, w1, u0 * w0);
@@ -194,9 +202,26 @@ __device__ __forceinline__ bool build_candidates_fast(const double* __restrict__
     sh.cval[tid] = valid ? v : rpp::b2d(0x7ff8000000000000ULL);
     __syncthreads();
     const int nchunk = (kraw - base) < TPB ? (kraw - base) : TPB;
-    if (valid) {
-#pragma unroll 4
-      for (int t = 0; t < nchunk; t++) unsure |= (t != tid) & (rpp::dabs(sh.cval[t] - v) <= tol);
+    {
+      // every valid hit of the chunk against every other: with G = ceil(nchunk / 64) groups of 64 hits, wave w checks for
+      // group w % G the partners t = part, part + P, ... (part = w / G of P = 4 / G parts), four LDS values per round trip
+      const int nch = __builtin_amdgcn_readfirstlane(nchunk);   // wave-uniform by construction: scalar loop control
+      const int G = (nch + 63) >> 6, P = G == 1 ? 4 : G == 2 ? 2 : 1;
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+      const int g = wv % G, part = wv / G;
+      if (part < P) {
+        const int me = 64 * g + lane;
+        const double mv_ = sh.cval[me];   // NaN unless a valid hit
+        bool close = false;
+        for (int t0 = 4 * part; t0 < nch; t0 += 4 * P) {
+          const double c0 = sh.cval[t0], c1 = sh.cval[t0 + 1], c2 = sh.cval[t0 + 2], c3 = sh.cval[t0 + 3];   // NaN past the chunk
+          close |= (t0 != me) & (rpp::dabs(c0 - mv_) <= tol);
+          close |= (t0 + 1 != me) & (rpp::dabs(c1 - mv_) <= tol);
+          close |= (t0 + 2 != me) & (rpp::dabs(c2 - mv_) <= tol);
+          close |= (t0 + 3 != me) & (rpp::dabs(c3 - mv_) <= tol);
+        }
+        unsure |= close;
+      }
     }
     const uint64_t mv = __ballot(valid);
     if (__ballot(unsure) != 0ull && lane == 0) sh.nrw2 = 1;
@@ -745,6 +770,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
     }
     if (tid == 64 && !(step + 1 < iters && it + 1 < c.max_iter)) sh.pk_ok = 0;
     __syncthreads();
+    PH(10);
     {
       const double ct = sh.ct, st = sh.st;
       const double nx0 = qx + E * ct, ny0 = qy + E * st;         // get_new_node :1219-1220
@@ -764,6 +790,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
       }
     }
     __syncthreads();
+    PH(11);
     const double nx = sh.nx, ny = sh.ny;
     s_eu++;
     s_er++;
@@ -787,6 +814,7 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         const double t2 = rg * rg * (1.0 + 1e-9) + 1.0;
         const uint32_t thr = t2 >= 4294967295.0 ? 0xffffffffu : (uint32_t)t2;
         const uint32_t qq = rppk::quant16(c, nx, ny);
+        PH(12);
         const double ax = sh.rx2, ay = sh.ry2;
         const bool pre = sh.pk_ok && ax >= q_glo && ax <= q_ghi && ay >= q_glo && ay <= q_ghi;
         if (pre) {
@@ -826,34 +854,78 @@ __global__ __launch_bounds__(TPB, WPS) void rrt_informed_kernel(Ctx c, const Inf
         // batches (4, 8, 16 ...): the first free one in rank order IS the reference's `min(d_list)` / `.index` pick
         // (:1125-1126); later ones are never tested.  atan2 / cos / sin (:1118, :1273-1274) are evaluated for tested
         // candidates only.  ufree: -1 not tested, 0 blocked, 1 free.  The rank lives in uey[] until the slot is tested.
+        int32_t* racc = reinterpret_cast<int32_t*>(sh.uey);   // rank accumulators (uey is free until a segment needs its exact form)
         for (int e = tid; e < nu; e += TPB) {
           const double de = rpp::py_hypot(nx - sh.ux[e], ny - sh.uy[e]);
           sh.ud[e] = de;
           sh.uex[e] = sh.ucost[e] + de;   // the candidate's cost :1120 (uex is free until a segment needs its exact form)
           sh.ufree[e] = -1;
+          racc[e] = 0;
         }
+        if (tid < 8 && nu + tid < NUI) sh.uex[nu + tid] = rpp::dinf();   // the rank loops read whole blocks of 4
         if (tid == 0) {
           sh.ntl = 0;
           sh.flag = 0x7fffffff;
         }
         __syncthreads();
+        PH(7);
         // rank + the first batch: the 4 cheapest candidates, and with them the candidates rewire (:1232-1246) will most
         // likely ask for -- those whose cost would improve if the cheapest candidate becomes the parent (the usual case).
         // That guess only decides WHEN a segment is tested: rewire below still tests whatever it needs and has no verdict for
         constexpr int B0 = 4;
-        for (int e = tid; e < nu; e += TPB) {
-          const double ce = sh.uex[e];
-          int rk = 0;
-          double cmin = rpp::dinf();
+        {
+          const int nus = __builtin_amdgcn_readfirstlane(nu);   // wave-uniform by construction: scalar loop control
+          if (nus <= TPB) {
+            // rank of candidate e = number of (cost, position) pairs below its own.  All four waves share the pairs: with
+            // G = ceil(nu / 64) groups of 64 candidates, wave w counts for group w % G the competitors j = part, part + P, ...
+            // (part = w / G of P = 4 / G parts), four LDS values per round trip, and adds its count to the candidate's
+            // accumulator; ties (equal costs) are rare and settled by position in the same loop
+            const int G = (nus + 63) >> 6, P = G == 1 ? 4 : G == 2 ? 2 : 1;
+            const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int g = wv % G, part = wv / G;
+            double cmin = rpp::dinf();
+            if (part < P) {
+              const int e = 64 * g + (tid & 63);
+              const double ce = e < nus ? sh.uex[e] : rpp::dinf();
+              int rk = 0;
+              for (int j0 = 4 * part; j0 < nus; j0 += 4 * P) {
+                const double c0 = sh.uex[j0], c1 = sh.uex[j0 + 1], c2 = sh.uex[j0 + 2], c3 = sh.uex[j0 + 3];   // padded with +inf
+                rk += (int)(c0 < ce) | ((int)(c0 == ce) & (int)(j0 < e));
+                rk += (int)(c1 < ce) | ((int)(c1 == ce) & (int)(j0 + 1 < e));
+                rk += (int)(c2 < ce) | ((int)(c2 == ce) & (int)(j0 + 2 < e));
+                rk += (int)(c3 < ce) | ((int)(c3 == ce) & (int)(j0 + 3 < e));
+                const double m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3, m = m01 < m23 ? m01 : m23;
+                cmin = m < cmin ? m : cmin;
+              }
+              if (e < nus && rk) atomicAdd(&racc[e], rk);
+            }
+            if ((tid & 63) == 0) sh.red_best[wv] = cmin;   // this wave's share of the cheapest cost
+            __syncthreads();
+            if (tid < nus) {
+              const int e = tid, rk = racc[e];
+              double cm = sh.red_best[0];
+#pragma unroll
+              for (int k = 1; k < NW; k++) cm = sh.red_best[k] < cm ? sh.red_best[k] : cm;
+              sh.urank[e] = (int16_t)rk;
+              if (rk < B0) sh.cflag[rk] = e;
+              if (rk < B0 || sh.ucost[e] > cm + sh.ud[e]) sh.tl[atomicAdd(&sh.ntl, 1)] = (int16_t)e;   // <= nu entries
+            }
+          } else {
+            for (int e = tid; e < nu; e += TPB) {
+              const double ce = sh.uex[e];
+              int rk = 0;
 #pragma unroll 4
-          for (int j = 0; j < nu; j++) {
-            const double cj = sh.uex[j];
-            rk += (cj < ce || (cj == ce && j < e)) ? 1 : 0;
-            cmin = cj < cmin ? cj : cmin;
+              for (int j = 0; j < nus; j++) {
+                const double cj = sh.uex[j];
+                rk += (int)(cj < ce) | ((int)(cj == ce) & (int)(j < e));
+              }
+              sh.urank[e] = (int16_t)rk;
+              if (rk < B0) {
+                sh.cflag[rk] = e;
+                sh.tl[atomicAdd(&sh.ntl, 1)] = (int16_t)e;
+              }
+            }
           }
-          sh.urank[e] = (int16_t)rk;
-          if (rk < B0) sh.cflag[rk] = e;
-          if (rk < B0 || (nu <= TPB && sh.ucost[e] > cmin + sh.ud[e])) sh.tl[atomicAdd(&sh.ntl, 1)] = (int16_t)e;   // <= max(B0, nu) entries
         }
         __syncthreads();
         PH(5);

@@ -24,7 +24,9 @@ s = h.get_stats()
 ph = h.get_phase_cycles()
 names = {0: "sample (when not read ahead)", 1: "nearest (prefetched answer / own pass / 2nd pass)", 2: "steer + extension collision (+ read-ahead draw)",
          3: "fused 16-bit pass (near + next nearest)", 4: "candidates: exact re-check + de-dup", 5: "choose_parent: hypot + rank",
-         6: "choose_parent: collision batches", 9: "append + rewire", 15: "goal bookkeeping + commit + loop"}
+         6: "choose_parent: collision batches", 9: "append + rewire", 15: "goal bookkeeping + commit + loop",
+         7: "choose_parent: hypot + cost sums", 10: "steer: x[ni] + atan2 + cos | sin | read-ahead", 11: "steer: node, hypot, goal test",
+         12: "pass set-up (radius, grid point)"}
 tot = float(ph.sum())
 print("instances", B, "max_iter", it, "kernel_ms", s["kernel_ms"])
 for k in sorted(names):
