@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stress parity (GPU box): many seeds per planner, GPU trees vs the golden-pinned oracle, bit for bit.
 Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 / STRESS_ONLY=moved run that block only,
-STRESS_ONLY=pose the rrt_05 / rrt_03 / rrt_07 blocks)"""
+STRESS_ONLY=pose the rrt_05 / rrt_03 / rrt_07 blocks, STRESS_ONLY=rrt07 the rrt_07 blocks)"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -102,7 +102,8 @@ if __name__ == "__main__":
                     ("curvature 1, step 0.2, radius 0, goal yaw 1.2, 1000 it",
                      {"curvature": 1.0, "step_size": 0.2, "robot_radius": 0.0, "max_iter": 1000,
                       "goal": np.array([10.0, 9.0, 1.2])}))
-        POSE = os.environ.get("STRESS_ONLY") == "pose"
+        POSE = os.environ.get("STRESS_ONLY") in ("pose", "rrt07")
+        R07 = os.environ.get("STRESS_ONLY") == "rrt07"
         for nm, upd in (() if os.environ.get("STRESS_ONLY") in ("moved", "pose") else rs_cases):
             g = dict(G06); g.update(upd)
             out = util.run_gpu_rrt_rs(g, seeds)
@@ -124,11 +125,12 @@ if __name__ == "__main__":
             print("TOTAL mismatches", total)
             sys.exit(1 if total else 0)
         # rrt_05
-        g = dict(G05); g["max_iter"] = 4000
-        out = util.run_gpu_dubins(g, seeds)
-        total += compare("rrt_05 driver, 4000 it", out["trees"], list(ex.map(o05, [(s, 4000) for s in seeds])))
+        if not R07:
+            g = dict(G05); g["max_iter"] = 4000
+            out = util.run_gpu_dubins(g, seeds)
+            total += compare("rrt_05 driver, 4000 it", out["trees"], list(ex.map(o05, [(s, 4000) for s in seeds])))
         # rrt_03, both samplers
-        for sob in (1, 0):
+        for sob in (() if R07 else (1, 0)):
             g = dict(G03); g["max_iter"] = 3000; g["sobol"] = sob
             out = util.run_gpu_rrt_dubins(g, seeds)
             total += compare("rrt_03 driver, 3000 it, sobol=%d" % sob, out["trees"],
@@ -143,9 +145,13 @@ if __name__ == "__main__":
             out = util.run_gpu_batch(kw, seeds)
             total += compare("rrt_04 driver map, 2000 it", out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
         # rrt_07
-        for gg, it, nm in ((G07, 3000, "C3-style map"), (G07D, 2000, "driver map")):
+        for gg, it, nm, sob in ((G07, 3000, "C3-style map", None), (G07D, 2000, "driver map", None),
+                                (G07, 8000, "C3-style map, Sobol sampler (informed phase from ~1200 it)", 1),
+                                (G07D, 2000, "driver map, Sobol sampler", 1)):
             kw7 = util.informed_kwargs_from_golden(gg)
             kw7["max_iter"] = it
+            if sob is not None:
+                kw7["sobol"] = sob
             out = util.run_gpu_informed(kw7, seeds)
             total += compare("rrt_07 %s, %d it" % (nm, it), out["trees"], list(ex.map(o07, [(s, kw7) for s in seeds])))
         # rrt_07, cluttered quarter map: most of the cheapest choose_parent candidates are blocked (the device's batches grow)
