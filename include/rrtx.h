@@ -27,7 +27,8 @@ extern "C" {
 
 #define RRTX_ABI_VERSION 4   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
                                 rrtx_copy_results_device, per-instance yaw and informed rotation; 4: rrtx_plan_many,
-                                rrtx_selfcheck, rrtx_stats.main_shape / main_f32 */
+                                rrtx_selfcheck, rrtx_stats.main_shape / main_f32, rrtx_plan_begin / _step, rrtx_set_launch_bound,
+                                RRTX_ST_REF_HANGS */
 
 enum {
   RRTX_PARTIAL = 1,        /* rrtx_plan only: the call completed, but at least one instance stopped with RRTX_ST_OVERFLOW,
@@ -64,7 +65,13 @@ enum { RRTX_ST_DONE = 1, RRTX_ST_PATH = 2, RRTX_ST_OVERFLOW = 4, RRTX_ST_PATH_TR
                                    is walked by the general kernel, to which rrtx_plan hands such instances over
                                    (rrtx_stats.replanned); kept as a guard */,
        RRTX_ST_REF_RAISES = 32  /* RRTX_ALGO_RS: the reference raises here (ZeroDivisionError :1183/:1207 or ValueError from
-                                   math.acos/asin) inside reeds_shepp_path_planning; the instance stops, no path */ };
+                                   math.acos/asin) inside reeds_shepp_path_planning; the instance stops, no path */,
+       RRTX_ST_REF_HANGS = 64   /* RRTX_ALGO_BITSTAR, set together with RRTX_ST_OVERFLOW: the reference does not terminate on
+                                   this instance.  plan() adds samples only `if iterations != 0` (rrt_08:215); when no edge
+                                   ever connects (a start walled in by obstacles: every connect() fails and `continue`s past
+                                   the iteration counter, :283) both queues run dry a second time with the tree, the samples
+                                   and the RNG unchanged, and the same round repeats for ever.  The device proves that at the
+                                   second arrival and stops the instance there */ };
 
 /* Constructor arguments of the reference classes (rrt_04:951-1000, rrt_01:32-69). */
 typedef struct rrtx_params {
@@ -159,6 +166,19 @@ int rrtx_set_instance_rotation(rrtx_handle* h, int32_t instance, const double* r
 /* replaces the body of RRT.planning(animation=False) for every instance; blocking.  Returns RRTX_OK, RRTX_PARTIAL
  * (see above) or a negative error. */
 int rrtx_plan(rrtx_handle* h);
+/* The same plan in BOUNDED launches (load balance / a service that must not wait for its slowest instance).
+ * rrtx_plan_begin uploads the instances' start state; every rrtx_plan_step queues ONE kernel launch over the instances that
+ * are not finished, waits for it and reports in *n_pending how many instances still need another launch (0 = the plan is
+ * complete: the step that reaches 0 also runs the overflow re-plans and returns what rrtx_plan would have returned).  A
+ * launch is bounded by rrtx_set_launch_bound (default: RRT* iteration kernel 131072 iterations, the other tree planners
+ * 32768, BIT* 20000 trips of plan()'s loop :243): an instance that has used its share stores its state on the device and is
+ * carried into the next launch -- results do not depend on the bound.  Between steps rrtx_get_results is valid: an instance
+ * with RRTX_ST_DONE in its status word is final, whatever the others still do.  rrtx_plan = begin + steps until 0.
+ * BIT* launches run persistent waves over a device-side work queue of the pending instances (rrt_bitstar_wave.hip.h). */
+int rrtx_plan_begin(rrtx_handle* h);
+int rrtx_plan_step(rrtx_handle* h, int32_t* n_pending);
+/* iterations (BIT*: loop trips) one launch may spend on one instance; not while a plan is in progress */
+int rrtx_set_launch_bound(rrtx_handle* h, int32_t iterations);
 /* Multi-GPU in one process ("one handle per device, driven from one process with N threads"): plans the n
  * handles concurrently, one host thread per handle (each bound to its handle's device; two handles may share a device),
  * and returns when all have finished.  rcs[i] (may be NULL) = what rrtx_plan(handles[i]) returned; the return value is

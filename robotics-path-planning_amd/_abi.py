@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 RRTX_ABI_VERSION = 4
 ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR, ALGO_RRT_DUBINS, ALGO_RS = 0, 1, 2, 3, 4, 5, 6
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
-ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC, ST_UNSUPPORTED, ST_REF_RAISES = 1, 2, 4, 8, 16, 32
+ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC, ST_UNSUPPORTED, ST_REF_RAISES, ST_REF_HANGS = 1, 2, 4, 8, 16, 32, 64
 ST_FAILED = ST_OVERFLOW | ST_UNSUPPORTED | ST_REF_RAISES   # the instance stopped without a result
 RRTX_PARTIAL = 1
 ERRORS = {1: "RRTX_PARTIAL", 0: "OK", -1: "RRTX_E_INVALID", -2: "RRTX_E_NO_DEVICE", -3: "RRTX_E_HIP", -4: "RRTX_E_CAPACITY",
@@ -25,7 +25,8 @@ EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obs
            "rrtx_get_rng_state", "rrtx_seed_instances", "rrtx_set_instance", "rrtx_set_instance_rotation", "rrtx_plan", "rrtx_get_tree",
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_copy_results_device", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_trace_kind", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
-           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw", "rrtx_selfcheck", "rrtx_plan_many"]
+           "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw", "rrtx_selfcheck", "rrtx_plan_many", "rrtx_plan_begin", "rrtx_plan_step",
+           "rrtx_set_launch_bound"]
 
 
 class Params(C.Structure):
@@ -104,6 +105,9 @@ def load():
     L.rrtx_get_path_yaw.argtypes = [vp, i32, vp, i32, C.POINTER(i32)]
     L.rrtx_selfcheck.argtypes = [i32, i32, vp]
     L.rrtx_plan_many.argtypes = [vp, i32, vp]
+    L.rrtx_plan_begin.argtypes = [vp]
+    L.rrtx_plan_step.argtypes = [vp, C.POINTER(i32)]
+    L.rrtx_set_launch_bound.argtypes = [vp, i32]
     for f in EXPORTS:
         if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
             getattr(L, f).restype = C.c_int
@@ -265,6 +269,21 @@ class Handle:
         if rc == RRTX_PARTIAL and strict:
             raise RrtxError("rrtx_plan: %s" % self.last_error())
         return rc
+
+    def set_launch_bound(self, iterations):
+        """Iterations (BIT*: trips of plan()'s loop) one kernel launch may spend on one instance."""
+        self._chk(self.L.rrtx_set_launch_bound(self._h, int(iterations)), "rrtx_set_launch_bound")
+
+    def plan_begin(self):
+        self._chk(self.L.rrtx_plan_begin(self._h), "rrtx_plan_begin")
+
+    def plan_step(self):
+        """One bounded launch; returns (return code, instances still pending).  pending == 0: the plan is complete and the
+        return code is rrtx_plan's (0 or RRTX_PARTIAL).  get_results() is valid between steps."""
+        n = C.c_int32()
+        rc = self.L.rrtx_plan_step(self._h, C.byref(n))
+        self._chk(rc, "rrtx_plan_step")
+        return rc, n.value
 
     def last_error(self):
         return self.L.rrtx_last_error(self._h).decode()

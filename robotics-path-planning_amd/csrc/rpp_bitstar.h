@@ -159,6 +159,7 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
   s.nv = 1;
   bit_informed_sample(c, s, rng, 200, s.g_goal);
   long guard = 0;
+  int seen0 = 0;
   while (s.iterations < c.max_iter && s.error == 0) {
     if (++guard > 4000000) {
       s.error = 2;
@@ -166,6 +167,15 @@ RPP_HD static inline void bitstar_plan(const BitCfg& c, BitState& s, RNG* rng) {
     }
     // ---- setup_sample :209-234
     if (s.nvq == 0 && s.neq == 0) {
+      if (s.iterations == 0) {
+        // samples are added only `if iterations != 0` (:215): a second arrival here before any edge has connected finds the
+        // tree, the samples and the RNG as they were the first time -- the reference repeats that round for ever (error 3)
+        if (seen0) {
+          s.error = 3;
+          break;
+        }
+        seen0 = 1;
+      }
       if (s.iterations != 0) {
         int mm = 100;
         if (s.found_goal) {

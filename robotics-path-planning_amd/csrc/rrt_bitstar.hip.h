@@ -24,6 +24,11 @@ struct BitArgs {
   double* out_g;             // per instance: g_goal
   double *tr_a, *tr_b;       // optional trace of instance trace_inst
   int32_t tr_cap, trace_inst;
+  // wave kernel: device-side work queue and launch bound (rrt_bitstar_wave.hip.h)
+  const int32_t* queue;      // pending instance ids of this launch (nullptr = 0 .. n_pending-1)
+  int32_t* qhead;            // atomic counter: next queue slot
+  int32_t n_pending, trip_bound;
+  int32_t* save_i;           // per instance: nvq, neq, guard lo / hi, seen0 of a carried instance
 };
 // (the arrays rrtx_get_tree / rrtx_get_path read back keep their offsets; the cached columns follow them)
 constexpr int64_t DSLAB = 3LL * SC + 3LL * LC + 5LL * VC + 2LL * EC + 2LL * PC + 2LL * EC + VC;
@@ -57,7 +62,7 @@ __global__ void bitstar_kernel(BitArgs a, rppk::Inst* inst, rppk::Result* result
   inst[i].iterations = s.iterations;
   inst[i].edges_unique = s.tr_n;
   inst[i].edges_ref = s.tr_n;
-  inst[i].status = 1 | (s.path_n > 0 ? 2 : 0) | (s.error == 2 ? 4 : 0);
+  inst[i].status = 1 | (s.path_n > 0 ? 2 : 0) | (s.error >= 2 ? 4 : 0) | (s.error == 3 ? 64 : 0);   // DONE, PATH, OVERFLOW, REF_HANGS
   results[i].path_cost = s.g_goal;
   results[i].n_nodes = s.nv;
   results[i].status = inst[i].status;

@@ -93,12 +93,27 @@ __device__ __forceinline__ void w_erase(T* a, int ri, int n) {
   }
 }
 
+// Persistent waves and a device-side work queue ("more instances than workgroup slots and a device-side work
+// queue"): the grid holds as many waves as the chip keeps resident, each pulls the next pending instance from an atomic
+// counter when its own is finished, so a batch larger than the resident set has no per-set tail and run lengths that differ
+// from instance to instance (BIT* depends on the start / goal pair) pack.  a.queue lists the pending instances (nullptr =
+// 0 .. n_pending-1).  A launch is BOUNDED: an instance that has made a.trip_bound trips of plan()'s loop (:243) stores its
+// whole state (LDS columns -> its slab, the scalars -> out_i / save_i) and is carried into the next launch (ST_CARRY in its
+// Inst status), where a wave picks it up again; the host re-queues what is not done (rrtx_api.hip).
+constexpr int ST_CARRY = 0x100;   // Inst::status only (never in a result record): state stored, to be resumed
+
 __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst* inst, rppk::Result* results,
                                                           int n_inst) {
   __shared__ ShB sh;
-  const int I = blockIdx.x;
   const int lane = threadIdx.x;
-  if (I >= n_inst) return;
+ for (;;) {
+  int slot = 0;
+  if (lane == 0) slot = atomicAdd(a.qhead, 1);
+  slot = __builtin_amdgcn_readfirstlane(slot);
+  if (slot >= a.n_pending) break;
+  const int I = a.queue ? a.queue[slot] : slot;
+  if (I < 0 || I >= n_inst) continue;
+  const bool resume = (inst[I].status & ST_CARRY) != 0;
   const rpp::BitCfg c = a.cfg[I];
   double* d = a.dslab + (int64_t)I * DSLAB;
   int32_t* q = a.islab + (int64_t)I * ISLAB;
@@ -134,24 +149,55 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
 
   // wave-uniform scalars
   int ns = 0, nv = 0, nte = 0, nvq = 0, neq = 0, path_n = 0, tr_n = 0, error = 0, iterations = 0, found_goal = 0;
+  int seen0 = 0;     // the queues have run dry once with iterations == 0 (see the hang test in the loop)
+  int trips = 0, carry = 0;
+  long guard = 0;
   double g_goal = rpp::dinf();
   const double inf = rpp::dinf();
   const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  double* g_vq = g_vpar + VC;                       // slab homes of the LDS columns (carry-over only)
+  double* g_vh = eq_hb + EC;
+  int32_t* g_te_a = g_vhasp + VC;
+  int32_t* g_te_b = g_vhasp + 2LL * VC;
+  int32_t* g_vq_i = eq_ai + EC;
+  int32_t* sv = a.save_i + 8 * I;
 
   const double start_id = rpp::bit_id(c, c.start[0], c.start[1]), goal_id = rpp::bit_id(c, c.goal[0], c.goal[1]);
-  if (lane == 0) {
-    sid[0] = goal_id;
-    sx[0] = c.goal[0];
-    sy[0] = c.goal[1];
-    sh.vid[0] = start_id;
-    sh.vg[0] = 0.0;
-    sh.vf[0] = rpp::bit_dist(c, start_id, goal_id);
-    sh.vh[0] = rpp::bit_dist(c, start_id, goal_id);
-    sh.vhasp[0] = 0;
-    sh.vpar[0] = -1.0;
+  if (!resume) {
+    if (lane == 0) {
+      sid[0] = goal_id;
+      sx[0] = c.goal[0];
+      sy[0] = c.goal[1];
+      sh.vid[0] = start_id;
+      sh.vg[0] = 0.0;
+      sh.vf[0] = rpp::bit_dist(c, start_id, goal_id);
+      sh.vh[0] = rpp::bit_dist(c, start_id, goal_id);
+      sh.vhasp[0] = 0;
+      sh.vpar[0] = -1.0;
+    }
+    ns = 1;
+    nv = 1;
+  } else {
+    const int32_t* o = a.out_i + 8 * I;
+    nv = o[0]; nte = o[1]; ns = o[2]; iterations = o[5]; tr_n = o[6]; found_goal = o[7];
+    nvq = sv[0]; neq = sv[1]; seen0 = sv[4];
+    guard = (long)(((uint64_t)(uint32_t)sv[3] << 32) | (uint64_t)(uint32_t)sv[2]);
+    g_goal = a.out_g[I];
+    for (int v = lane; v < VL; v += 64) {
+      if (v < nv) {
+        sh.vid[v] = g_vid[v]; sh.vg[v] = g_vg[v]; sh.vf[v] = g_vf[v]; sh.vpar[v] = g_vpar[v]; sh.vh[v] = g_vh[v];
+        sh.vhasp[v] = g_vhasp[v];
+      }
+      if (v < nvq) {
+        sh.vq[v] = g_vq[v];
+        sh.vq_i[v] = g_vq_i[v];
+      }
+      if (v < nte) {
+        sh.te_a[v] = g_te_a[v];
+        sh.te_b[v] = g_te_b[v];
+      }
+    }
   }
-  ns = 1;
-  nv = 1;
   wsync();
 
   // informed_sample(m, cMax, ...) :397-420 followed by self.samples.update(...)
@@ -238,16 +284,30 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
     wsync();
   };
 
-  informed_sample(200, g_goal);
+  if (!resume) informed_sample(200, g_goal);
 
-  long guard = 0;
   while (iterations < c.max_iter && error == 0) {
+    if (trips++ >= a.trip_bound) {   // this launch's share is used up: store the state, another launch resumes here
+      carry = 1;
+      break;
+    }
     if (++guard > 4000000) {
       error = 2;
       break;
     }
     // ---- setup_sample :209-234
     if (nvq == 0 && neq == 0) {
+      if (iterations == 0) {
+        // The reference adds samples only `if iterations != 0` (:215): while no edge has ever connected (a start walled in by
+        // obstacles: every connect() fails and `continue`s past the iteration counter, :283) it comes back here with the
+        // tree, the samples and the RNG exactly as they were the first time -- plan() then repeats the same round for ever.
+        // The second arrival proves it; the instance ends at once instead of spinning up to the trip guard.
+        if (seen0) {
+          error = 3;
+          break;
+        }
+        seen0 = 1;
+      }
       if (iterations != 0) {
         int mm = 100;
         if (found_goal) {
@@ -550,6 +610,41 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
     iterations++;
   }
 
+  if (carry) {
+    // ---- carried into the next launch: LDS columns -> slab, scalars -> out_i / save_i, RNG -> Inst
+    wsync();
+    for (int v = lane; v < VL; v += 64) {
+      if (v < nv) {
+        g_vid[v] = sh.vid[v]; g_vg[v] = sh.vg[v]; g_vf[v] = sh.vf[v]; g_vpar[v] = sh.vpar[v]; g_vh[v] = sh.vh[v];
+        g_vhasp[v] = sh.vhasp[v];
+      }
+      if (v < nvq) {
+        g_vq[v] = sh.vq[v];
+        g_vq_i[v] = sh.vq_i[v];
+      }
+      if (v < nte) {
+        g_te_a[v] = sh.te_a[v];
+        g_te_b[v] = sh.te_b[v];
+      }
+    }
+    for (int i = lane; i < 624; i += 64) inst[I].rng.mt[i] = sh.rng.mt[i];
+    if (lane == 0) {
+      inst[I].rng.pos = sh.rng.pos;
+      int32_t* o = a.out_i + 8 * I;
+      o[0] = nv; o[1] = nte; o[2] = ns; o[3] = 0; o[4] = 0; o[5] = iterations; o[6] = tr_n; o[7] = found_goal;
+      sv[0] = nvq; sv[1] = neq; sv[2] = (int32_t)(uint32_t)((uint64_t)guard & 0xffffffffu);
+      sv[3] = (int32_t)(uint32_t)((uint64_t)guard >> 32); sv[4] = seen0;
+      a.out_g[I] = g_goal;
+      inst[I].n = nv;
+      inst[I].it = iterations;
+      inst[I].status = ST_CARRY;
+      results[I].path_cost = g_goal;
+      results[I].n_nodes = nv;
+      results[I].status = 0;
+    }
+    wsync();
+    continue;   // next pending instance
+  }
   // ---- find_final_path :333-347
   if (!error) {
     int np = 0;
@@ -616,11 +711,13 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
     inst[I].iterations = iterations;
     inst[I].edges_unique = tr_n;
     inst[I].edges_ref = tr_n;
-    inst[I].status = 1 | (path_n > 0 ? 2 : 0) | (error == 2 ? 4 : 0);
+    inst[I].status = 1 | (path_n > 0 ? 2 : 0) | (error >= 2 ? 4 : 0) | (error == 3 ? 64 : 0);   // DONE, PATH, OVERFLOW, REF_HANGS
     results[I].path_cost = g_goal;
     results[I].n_nodes = nv;
     results[I].status = inst[I].status;
   }
+  wsync();   // the LDS columns are reused by the next instance of the queue
+ }
 }
 
 }  // namespace rppb

@@ -64,6 +64,19 @@ struct rrtx_handle {
   int64_t phase[16] = {0};
   std::string err;
   std::vector<void*> allocs;
+  // one rrtx_plan in progress (rrtx_plan_begin / rrtx_plan_step; rrtx_plan = begin + steps until nothing is pending)
+  struct Run {
+    int stage = 0;   // 0 none, 1 RRT* iteration-kernel launches, 2 launches of the planner's main kernel
+    std::chrono::steady_clock::time_point t0;
+    double kms = 0.0, kms_main = -1.0;
+    int64_t launches = 0, launches_main = 0, steps = 0, v2_done_it = 0;
+    bool use_v2 = false, v2_f32 = false, bit_wave = false;
+    int v2_tpb = 0;
+    std::vector<Result> res;
+    std::vector<int32_t> pending;   // BIT*: instances not finished yet (the device-side work queue of the next launch)
+  } run;
+  int32_t *bit_queue = nullptr, *bit_qhead = nullptr;   // BIT*: device copy of `pending`, queue head counter
+  int bit_trip_bound = 20000;    // BIT*: trips of plan()'s loop per instance and launch (rrt_bitstar_wave.hip.h)
   int chunk_iters = 32768;       // iterations per launch of the other planner kernels
   int32_t* inst_map = nullptr;   // device: instance ids of a partial re-plan (overflow retry)
   // pose planners: where an instance's edge polylines live -- the handle's pool (slab = instance), or a larger pool
@@ -125,8 +138,8 @@ static int dalloc(rrtx_handle* h, T** p, size_t count) {
 // ---- RRT* (rrt_04, search_until_max_iter): iteration-kernel launches ------------------------------------------------
 // One pass of the latency-lean iteration kernel over `nblk` instances (c.inst_map selects them; nullptr = 0..nblk-1),
 // in chunks of h->v2_chunk_iters iterations, workgroup shape tpb in {64, 128, 256}.
-static int launch_rrt_star_v2(rrtx_handle* h, const Ctx& c, int nblk, int tpb, bool f32, double* kms, int64_t* launches) {
-  for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->v2_chunk_iters) {
+static int launch_rrt_star_v2_once(rrtx_handle* h, const Ctx& c, int nblk, int tpb, bool f32, double* kms, int64_t* launches) {
+  {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (tpb == 64) {
       if (f32)
@@ -151,6 +164,13 @@ static int launch_rrt_star_v2(rrtx_handle* h, const Ctx& c, int nblk, int tpb, b
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     *kms += ms;
     (*launches)++;
+  }
+  return RRTX_OK;
+}
+static int launch_rrt_star_v2(rrtx_handle* h, const Ctx& c, int nblk, int tpb, bool f32, double* kms, int64_t* launches) {
+  for (int64_t done_it = 0; done_it < c.max_iter; done_it += h->v2_chunk_iters) {
+    int rc = launch_rrt_star_v2_once(h, c, nblk, tpb, f32, kms, launches);
+    if (rc) return rc;
   }
   return RRTX_OK;
 }
@@ -496,9 +516,20 @@ int rrtx_enable_trace(rrtx_handle* h, int32_t instance) {
   return RRTX_OK;
 }
 
-int rrtx_plan(rrtx_handle* h) {
+static int plan_finish(rrtx_handle* h);
+
+int rrtx_plan_begin(rrtx_handle* h) {
   if (!h) return RRTX_E_INVALID;
-  auto t0 = std::chrono::steady_clock::now();
+  h->run = rrtx_handle::Run();
+  rrtx_handle::Run& R = h->run;
+  double &kms = R.kms, &kms_main = R.kms_main;
+  int64_t &launches = R.launches, &launches_main = R.launches_main;
+  std::vector<Result>& res = R.res;
+  bool &use_v2 = R.use_v2, &v2_f32 = R.v2_f32;
+  int& v2_tpb = R.v2_tpb;
+  (void)kms; (void)kms_main; (void)launches; (void)launches_main; (void)res; (void)use_v2; (void)v2_f32; (void)v2_tpb;
+  R.t0 = std::chrono::steady_clock::now();
+  h->planned = false;
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipDeviceSynchronize());   // uploads made through the null stream (obstacles, tables) are complete
   Ctx& c = h->c;
@@ -556,9 +587,7 @@ int rrtx_plan(rrtx_handle* h) {
   }
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  double kms = 0.0, kms_main = -1.0;
-  int64_t launches = 0, launches_main = 0;
-  std::vector<Result> res(B);
+  res.assign(B, Result());
   if (c.algo == RRTX_ALGO_BITSTAR) {
     // BIT*: one launch, one lane per instance (rrt_bitstar.hip.h); obstacle thresholds are size ** 2 (rrt_08:381)
     for (int i = 0; i < B; i++) {
@@ -575,28 +604,23 @@ int rrtx_plan(rrtx_handle* h) {
       h->ba.tr_cap = 1 << 16;
     }
     h->ba.trace_inst = h->trace_inst;
-    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     // one wave per instance when the per-vertex state fits LDS (rrt_bitstar_wave.hip.h); else one lane per instance
     const char* bk = getenv("RRTX_BITSTAR");
-    const bool wave = c.m <= rppb::OB && c.max_iter + 2 <= rppb::VL && !(bk && !strcmp(bk, "lane"));
-    if (wave)
-      hipLaunchKernelGGL(rppb::bitstar_wave_kernel, dim3(B), dim3(64), 0, h->stream, h->ba, c.inst, c.results, B);
-    else
-      hipLaunchKernelGGL(rppb::bitstar_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->ba, c.inst, c.results, B);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
-    kms += ms;
-    launches++;
+    R.bit_wave = c.m <= rppb::OB && c.max_iter + 2 <= rppb::VL && !(bk && !strcmp(bk, "lane"));
+    if (!h->bit_queue) {
+      int rc2;
+      if ((rc2 = dalloc(h, &h->bit_queue, B))) return rc2;
+      if ((rc2 = dalloc(h, &h->bit_qhead, 1))) return rc2;
+      if ((rc2 = dalloc(h, &h->ba.save_i, (size_t)8 * B))) return rc2;
+    }
+    if (const char* e = getenv("RRTX_BITSTAR_TRIPS")) h->bit_trip_bound = atoi(e) > 0 ? atoi(e) : 20000;
+    R.pending.resize(B);
+    for (int i = 0; i < B; i++) R.pending[i] = i;
   }
   // RRT* with search_until_max_iter: the latency-lean iteration kernel runs every iteration; the general kernel
   // below then only performs the final goal search (rrt_04:1080-1084).  RRTX_KERNEL=v1 forces the general kernel.
   const char* kv = getenv("RRTX_KERNEL");
-  const bool use_v2 = c.algo == RRTX_ALGO_RRT_STAR && c.until_max && !(kv && !strcmp(kv, "v1"));
-  int v2_tpb = 0;
-  bool v2_f32 = false;
+  use_v2 = c.algo == RRTX_ALGO_RRT_STAR && c.until_max && !(kv && !strcmp(kv, "v1"));
   if (use_v2) {
     // workgroup shape: fewer threads per instance once more instances want to be resident (8 / 16 workgroups per CU),
     // as long as the shape's obstacle tile and near-candidate capacity fit the problem
@@ -614,10 +638,6 @@ int rrtx_plan(rrtx_handle* h) {
     if (const char* e = getenv("RRTX_F32")) f32 = f32 && atoi(e) != 0;
     v2_tpb = tpb;
     v2_f32 = f32;
-    int rc2 = launch_rrt_star_v2(h, c, B, tpb, f32, &kms, &launches);
-    if (rc2) return rc2;
-    kms_main = kms;
-    launches_main = launches;
   }
   if (c.algo == RRTX_ALGO_INFORMED) {
     std::vector<double> inf(B, INFINITY);
@@ -651,7 +671,86 @@ int rrtx_plan(rrtx_handle* h) {
     }
     HIPCHK(h, hipMemcpyAsync(h->d_iargs, h->iargs.data(), sizeof(rppi::InformedArgs) * B, hipMemcpyHostToDevice, h->stream));
   }
-  for (;;) {
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  R.stage = use_v2 ? 1 : 2;
+  return RRTX_OK;
+}
+
+int rrtx_plan_step(rrtx_handle* h, int32_t* n_pending) {
+  if (!h) return RRTX_E_INVALID;
+  if (h->run.stage == 0) return RRTX_E_STATE;
+  rrtx_handle::Run& R = h->run;
+  double &kms = R.kms, &kms_main = R.kms_main;
+  int64_t &launches = R.launches, &launches_main = R.launches_main;
+  std::vector<Result>& res = R.res;
+  bool &use_v2 = R.use_v2, &v2_f32 = R.v2_f32;
+  int& v2_tpb = R.v2_tpb;
+  (void)kms; (void)kms_main; (void)launches; (void)launches_main; (void)res; (void)use_v2; (void)v2_f32; (void)v2_tpb;
+  HIPCHK(h, hipSetDevice(h->device));
+  Ctx& c = h->c;
+  const int B = h->n_inst;
+  R.steps++;
+  if (n_pending) *n_pending = B;
+  if (R.stage == 1) {
+    // RRT* (rrt_04, search_until_max_iter): one launch of the iteration kernel = v2_chunk_iters iterations of every instance
+    int rc2 = launch_rrt_star_v2_once(h, c, B, v2_tpb, v2_f32, &kms, &launches);
+    if (rc2) return rc2;
+    R.v2_done_it += h->v2_chunk_iters;
+    if (R.v2_done_it >= c.max_iter) {
+      kms_main = kms;
+      launches_main = launches;
+      R.stage = 2;   // the general kernel then performs the final goal search (rrt_04:1080-1084)
+    }
+    return RRTX_OK;
+  }
+  if (c.algo == RRTX_ALGO_BITSTAR) {
+    // One BOUNDED launch over the pending instances: persistent waves pull them from the device-side queue; an instance
+    // that uses up its trips is carried over (its state stays in its slab) and queued again for the next launch
+    const int np = (int)R.pending.size();
+    const int32_t zero = 0;
+    HIPCHK(h, hipMemcpyAsync(h->bit_queue, R.pending.data(), sizeof(int32_t) * np, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->bit_qhead, &zero, sizeof(int32_t), hipMemcpyHostToDevice, h->stream));
+    rppb::BitArgs ba = h->ba;
+    ba.queue = h->bit_queue;
+    ba.qhead = h->bit_qhead;
+    ba.n_pending = np;
+    ba.trip_bound = h->bit_trip_bound;
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    if (R.bit_wave) {
+      // as many waves as the chip keeps resident (LDS: 9 workgroups per CU), never more than there are instances
+      hipDeviceProp_t prop;
+      HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+      int grid = prop.multiProcessorCount * 9;
+      if (const char* e = getenv("RRTX_BITSTAR_GRID")) grid = atoi(e) > 0 ? atoi(e) : grid;
+      if (grid > np) grid = np;
+      hipLaunchKernelGGL(rppb::bitstar_wave_kernel, dim3(grid), dim3(64), 0, h->stream, ba, c.inst, c.results, B);
+    } else {
+      hipLaunchKernelGGL(rppb::bitstar_kernel, dim3((B + 63) / 64), dim3(64), 0, h->stream, ba, c.inst, c.results, B);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipMemcpyAsync(res.data(), c.results, sizeof(Result) * B, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    kms += ms;
+    launches++;
+    std::vector<int32_t> left;
+    for (int32_t i : R.pending)
+      if (!(res[i].status & RRTX_ST_DONE)) left.push_back(i);
+    R.pending.swap(left);
+    if (n_pending) *n_pending = (int32_t)R.pending.size();
+    if (!R.pending.empty()) {
+      if (launches > 4000000LL / h->bit_trip_bound + 16) {
+        h->err = "BIT* kernel did not converge to DONE";
+        return RRTX_E_STATE;
+      }
+      return RRTX_OK;
+    }
+    if (n_pending) *n_pending = 0;
+    return plan_finish(h);
+  }
+  {
     HIPCHK(h, hipEventRecord(h->ev0, h->stream));
     if (c.algo == RRTX_ALGO_INFORMED)
       hipLaunchKernelGGL((rppi::rrt_informed_kernel<rppi::NUI_SMALL, 4>), dim3(B), dim3(rppi::TPB), 0, h->stream, c,
@@ -670,18 +769,34 @@ int rrtx_plan(rrtx_handle* h) {
     HIPCHK(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
     kms += ms;
     launches++;
-    bool all = true;
+    int left = 0;
     for (int i = 0; i < B; i++)
-      if (!(res[i].status & RRTX_ST_DONE)) {
-        all = false;
-        break;
+      if (!(res[i].status & RRTX_ST_DONE)) left++;
+    if (n_pending) *n_pending = left;
+    if (left) {
+      if (launches > (int64_t)h->p.max_iter / h->chunk_iters + 8 + launches_main) {
+        h->err = "planner kernel did not converge to DONE";
+        return RRTX_E_STATE;
       }
-    if (all) break;
-    if (launches > (int64_t)h->p.max_iter / h->chunk_iters + 8) {
-      h->err = "planner kernel did not converge to DONE";
-      return RRTX_E_STATE;
+      return RRTX_OK;
     }
   }
+  return plan_finish(h);
+}
+
+// Everything after the last instance has finished its main kernel: re-plans of instances that outgrew a fixed table, the
+// counters, the return code
+static int plan_finish(rrtx_handle* h) {
+  rrtx_handle::Run& R = h->run;
+  double &kms = R.kms, &kms_main = R.kms_main;
+  int64_t &launches = R.launches, &launches_main = R.launches_main;
+  std::vector<Result>& res = R.res;
+  bool &use_v2 = R.use_v2, &v2_f32 = R.v2_f32;
+  int& v2_tpb = R.v2_tpb;
+  (void)kms; (void)kms_main; (void)launches; (void)launches_main; (void)res; (void)use_v2; (void)v2_f32; (void)v2_tpb;
+  Ctx& c = h->c;
+  const int B = h->n_inst;
+  R.stage = 0;
   // RRT* iteration kernel: an instance whose near set outgrew the LDS candidate table of its workgroup shape
   // (RRTX_ST_OVERFLOW) is planned again, from its staged start state, on the next larger shape (44 -> 128 -> 256
   // candidates), and finally by the general kernel (512).  Same results as a first plan on that shape: every shape
@@ -927,7 +1042,7 @@ int rrtx_plan(rrtx_handle* h) {
                         : c.algo == RRTX_ALGO_BITSTAR  ? 64
                                                        : rppk::TPB;
   s.main_f32 = use_v2 ? (v2_f32 ? 1 : 0) : 0;
-  s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  s.plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - R.t0).count();
   h->planned = true;
   // Per-instance conditions are per-instance results: the status word of each instance carries them
   // (rrtx_get_results), the other instances' trees are complete and valid.
@@ -943,6 +1058,29 @@ int rrtx_plan(rrtx_handle* h) {
     h->err += "the affected instances carry the bit in their status word and have no result, all others are complete";
     return RRTX_PARTIAL;
   }
+  return RRTX_OK;
+}
+
+int rrtx_plan(rrtx_handle* h) {
+  int rc = rrtx_plan_begin(h);
+  if (rc < 0) return rc;
+  int32_t pending = 1;
+  while (h->run.stage != 0) {
+    rc = rrtx_plan_step(h, &pending);
+    if (rc < 0) {
+      h->run.stage = 0;
+      return rc;
+    }
+  }
+  return rc;
+}
+
+int rrtx_set_launch_bound(rrtx_handle* h, int32_t iterations) {
+  if (!h || iterations < 1) return RRTX_E_INVALID;
+  if (h->run.stage != 0) return RRTX_E_STATE;
+  h->chunk_iters = iterations;
+  h->v2_chunk_iters = iterations;
+  h->bit_trip_bound = iterations;
   return RRTX_OK;
 }
 
@@ -1076,7 +1214,7 @@ int rrtx_get_path(rrtx_handle* h, int32_t instance, double* xy, int32_t cap_poin
 
 int rrtx_get_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status) {
   if (!h) return RRTX_E_INVALID;
-  if (!h->planned) return RRTX_E_STATE;
+  if (!h->planned && h->run.stage == 0) return RRTX_E_STATE;   // between steps of a plan: the records of the finished instances are final
   HIPCHK(h, hipSetDevice(h->device));
   std::vector<Result> r(h->n_inst);
   HIPCHK(h, hipMemcpy(r.data(), h->c.results, sizeof(Result) * h->n_inst, hipMemcpyDeviceToHost));

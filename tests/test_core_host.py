@@ -72,7 +72,7 @@ def test_python_binding_mirrors_the_header():
     st = dict((k, int(v)) for k, v in re.findall(r"(RRTX_ST_[A-Z_]+) = (\d+)", hdr))
     assert st == {"RRTX_ST_DONE": A.ST_DONE, "RRTX_ST_PATH": A.ST_PATH, "RRTX_ST_OVERFLOW": A.ST_OVERFLOW,
                   "RRTX_ST_PATH_TRUNC": A.ST_PATH_TRUNC, "RRTX_ST_UNSUPPORTED": A.ST_UNSUPPORTED,
-                  "RRTX_ST_REF_RAISES": A.ST_REF_RAISES}
+                  "RRTX_ST_REF_RAISES": A.ST_REF_RAISES, "RRTX_ST_REF_HANGS": A.ST_REF_HANGS}
     rcs = dict((k, int(v)) for k, v in re.findall(r"(RRTX_(?:OK|PARTIAL|E_[A-Z_]+)) = (-?\d+)", hdr))
     assert rcs["RRTX_PARTIAL"] == A.RRTX_PARTIAL == 1 and rcs["RRTX_OK"] == 0
     assert {v: k for k, v in rcs.items()} == {k: (v if v != "OK" else "RRTX_OK") for k, v in A.ERRORS.items()}

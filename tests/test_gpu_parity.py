@@ -859,9 +859,10 @@ def test_gpu_input_limits(gpu):
 @pytest.mark.timeout(180)
 def test_gpu_bitstar_start_inside_an_obstacle_ends_as_overflow(gpu):
     """A start inside a circle: every connect() of rrt_08's plan() fails, its `continue` (:283) skips the iteration
-    counter and the reference loops for ever, sampling 100 more points each time the queues run dry (measured: no
-    return within 20 minutes).  The device must not: the instance fills its sample slab and stops with
-    RRTX_ST_OVERFLOW (the oracle ends the same way), the call returns RRTX_PARTIAL, and the other instance of the
+    counter, and because samples are only added `if iterations != 0` (:215) the reference repeats the same round for ever
+    (measured: no return within 20 minutes).  The device proves that at the second time both queues run dry with nothing
+    changed and stops the instance at once with RRTX_ST_OVERFLOW | RRTX_ST_REF_HANGS (round 2: after 4 million trips, 18 s
+    on one wave; the oracle gives up at its own trip guard), the call returns RRTX_PARTIAL, and the other instance of the
     batch is complete and equal to the oracle."""
     import oracle
     import rrt_amd
@@ -880,9 +881,12 @@ def test_gpu_bitstar_start_inside_an_obstacle_ends_as_overflow(gpu):
             cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])
             h.set_instance(i, starts[i], goals[i])
             h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        import time
+        t0 = time.perf_counter()
         h.plan(strict=False)
+        assert time.perf_counter() - t0 < 2.0
         st = h.get_results()[2]
-        assert st[0] & A.ST_OVERFLOW and not (st[1] & A.ST_FAILED)
+        assert st[0] & A.ST_OVERFLOW and st[0] & A.ST_REF_HANGS and not (st[1] & A.ST_FAILED)
         r = oracle.plan_bitstar(starts[1], goals[1], obst, [-2, 15], 40, seed=42)
         x, y, cost, parent = h.get_tree(1)
         gx, gy = _bit_coords(r["vertex_ids"])
@@ -1424,3 +1428,182 @@ def test_gpu_informed_nodes_leaving_the_16bit_grid_fall_back(gpu, monkeypatch):
             assert (out["paths"][i] is None) == (r["path"] is None)
         if env.get("RRTX_Q16") == "0":
             assert out["stats"]["q16_fallbacks"] == 0
+
+
+def _c4_instances(lo, hi):
+    """Instances lo..hi-1 of the C4 generator (bench.py / SURVEY 8d): start / goal from random.Random(2000 + i) outside
+    the obstacles, planner seed 1000 + i."""
+    import random
+    obst = [(5, 5, 0.5), (9, 6, 1), (7, 5, 1), (1, 5, 1), (3, 6, 1), (7, 9, 1)]
+
+    def free_point(rng):
+        while True:
+            x, y = rng.uniform(-1, 14), rng.uniform(-1, 14)
+            if all((x - ox) ** 2 + (y - oy) ** 2 > r ** 2 for ox, oy, r in obst):
+                return [x, y]
+    starts, goals, seeds = [], [], []
+    for i in range(lo, hi):
+        rng = random.Random(2000 + i)
+        starts.append(free_point(rng))
+        goals.append(free_point(rng))
+        seeds.append(1000 + i)
+    return obst, starts, goals, seeds
+
+
+@pytest.mark.gpu
+def test_gpu_bitstar_bounded_launches_carry_instances_over(gpu, monkeypatch):
+    """BIT* launches are bounded and run persistent waves over a device-side work queue.  With
+    RRTX_BITSTAR_TRIPS=37 no instance finishes in one launch: each stores its whole state (LDS columns, queues, RNG) when
+    its trips are used up, is queued again, and another wave resumes it -- dozens of times.  RRTX_BITSTAR_GRID=5 makes five
+    persistent waves pull all 96 instances from the queue.  Trees, paths, popped-edge traces and RNG states equal the
+    unbounded single-launch run's and the reference goldens."""
+    obst, starts, goals, seeds = _c4_instances(0, 96)
+    ref = util.run_gpu_bitstar(obst, [-2.0, 15.0], 80, seeds, starts, goals, trace_instance=7)
+    assert ref["stats"]["launches"] == 1
+    for env in ({"RRTX_BITSTAR_TRIPS": "37"}, {"RRTX_BITSTAR_GRID": "5"}, {"RRTX_BITSTAR_TRIPS": "11", "RRTX_BITSTAR_GRID": "3"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = util.run_gpu_bitstar(obst, [-2.0, 15.0], 80, seeds, starts, goals, trace_instance=7)
+        for k in env:
+            monkeypatch.delenv(k)
+        if "RRTX_BITSTAR_TRIPS" in env:
+            assert out["stats"]["launches"] > 10
+        for a, b in zip(out["results"], ref["results"]):
+            assert np.array_equal(a, b), env
+        for i in range(len(seeds)):
+            util.assert_tree_equal(out["trees"][i], ref["trees"][i], "%s instance %d" % (env, i))
+            p, q = out["paths"][i], ref["paths"][i]
+            assert (p is None) == (q is None) and (p is None or np.array_equal(p, q))
+            assert out["rng"][i] == ref["rng"][i]
+        assert np.array_equal(out["trace"][0], ref["trace"][0]) and np.array_equal(out["trace"][1], ref["trace"][1])
+        assert out["stats"]["edges_unique"] == ref["stats"]["edges_unique"]
+    monkeypatch.setenv("RRTX_BITSTAR_TRIPS", "23")
+    for path in util.golden_files("rrt08")[:4]:
+        g = util.load_golden(path)
+        out = util.run_gpu_bitstar([tuple(float(v) for v in o) for o in g["obstacles"]], [float(v) for v in g["rand_area"]],
+                                   int(g["max_iter"]), [int(g["seed"])], [[float(v) for v in g["start"]]],
+                                   [[float(v) for v in g["goal"]]], trace_instance=0)
+        assert np.array_equal(out["trace"][0], g["tr_e0"]) and np.array_equal(out["trace"][1], g["tr_e1"])
+        gx, gy = _bit_coords(g["vertex_ids"])
+        x, y, cost, parent = out["trees"][0]
+        assert np.array_equal(x, gx) and np.array_equal(y, gy) and np.array_equal(cost, g["g_scores"])
+        assert out["rng"][0][1][624] == int(g["rng_pos_after"]) and out["rng"][0][1][0] == int(g["rng_word0_after"])
+
+
+@pytest.mark.gpu
+def test_gpu_bitstar_walled_in_instance_does_not_hold_the_batch(gpu):
+    """4 096 C4 instances, one of them with its start inside an obstacle (the reference never returns from it; round 2:
+    18 s on one wave = the time of the whole batch).  The whole batch now plans in well under half a second: the straggler
+    ends RRTX_ST_OVERFLOW | RRTX_ST_REF_HANGS, every other instance completes and the batch equals the run without it."""
+    import time
+    import rrt_amd
+    A = rrt_amd._abi
+    obst, starts, goals, seeds = _c4_instances(0, 4096)
+    bad = 1234
+    starts_b = [list(v) for v in starts]
+    starts_b[bad] = [7.0, 5.0]                      # inside the circle (7, 5, 1)
+    bp = rrt_amd.BatchPlanner("bitstar", seeds, starts[0], goals[0], obst, [-2.0, 15.0], max_iter=80, starts=starts_b,
+                              goals=goals)
+    ok = rrt_amd.BatchPlanner("bitstar", seeds, starts[0], goals[0], obst, [-2.0, 15.0], max_iter=80, starts=starts,
+                              goals=goals)
+    try:
+        bp.plan()                                    # first call pages the code object in
+        bp.h.seed_instances(seeds)
+        t0 = time.perf_counter()
+        pc, nn, st = bp.plan()
+        dt = time.perf_counter() - t0
+        assert dt < 0.5, dt
+        assert bp.partial and st[bad] & A.ST_OVERFLOW and st[bad] & A.ST_REF_HANGS
+        assert [i for i, _ in bp.failed()] == [bad]
+        pc0, nn0, st0 = ok.plan()
+        keep = np.arange(4096) != bad
+        assert np.array_equal(pc[keep], pc0[keep]) and np.array_equal(nn[keep], nn0[keep]) and np.array_equal(st[keep], st0[keep])
+        assert (st[keep] & A.ST_DONE).all()
+    finally:
+        bp.close()
+        ok.close()
+
+
+@pytest.mark.gpu
+def test_gpu_plan_in_bounded_steps(gpu):
+    """rrtx_plan_begin / rrtx_plan_step: a plan as a sequence of bounded launches (rrtx_set_launch_bound).  Between steps
+    the result records of finished instances are final; the completed plan equals rrtx_plan's.  rrt_04 iteration kernel +
+    final goal search, rrt_07, and BIT* (where run lengths differ from instance to instance, so the pending count falls step
+    by step)."""
+    import rrt_amd
+    A = rrt_amd._abi
+    # BIT*
+    obst, starts, goals, seeds = _c4_instances(0, 64)
+    ref = util.run_gpu_bitstar(obst, [-2.0, 15.0], 80, seeds, starts, goals)
+    c_min, c = rrt_amd.bitstar_rotation(starts[0], goals[0])
+    h = A.Handle(A.ALGO_BITSTAR, starts[0], goals[0], [-2.0, 15.0], 2.0, 1.0, 0, 80, n_instances=64,
+                 informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+    try:
+        h.set_obstacles(obst)
+        h.seed_instances(seeds)
+        for i in range(64):
+            cm, ci = rrt_amd.bitstar_rotation(starts[i], goals[i])
+            h.set_instance(i, starts[i], goals[i])
+            h.set_instance_rotation(i, [ci[0, 0], ci[0, 1], ci[1, 0], ci[1, 1]], cm)
+        h.set_launch_bound(150)
+        h.plan_begin()
+        pend, done_at = [], {}
+        while True:
+            rc, n = h.plan_step()
+            pend.append(n)
+            st = h.get_results()[2]
+            for i in np.nonzero(st & A.ST_DONE)[0]:
+                done_at.setdefault(int(i), (len(pend), h.get_results()[0][i]))
+            if n == 0:
+                break
+        assert len(pend) > 3 and pend == sorted(pend, reverse=True) and pend[-1] == 0
+        assert any(0 < n < 64 for n in pend)         # instances finish in different launches
+        pc, nn, st = h.get_results()
+        for a, b in zip((pc, nn, st), ref["results"]):
+            assert np.array_equal(a, b)
+        for i, (_, cost_then) in done_at.items():
+            assert cost_then == pc[i] or (np.isinf(cost_then) and np.isinf(pc[i]))     # final when first seen DONE
+        for i in range(64):
+            util.assert_tree_equal(h.get_tree(i), ref["trees"][i], "BIT* instance %d" % i)
+    finally:
+        h.close()
+    # rrt_04 (iteration kernel in 500-iteration launches, then the goal search) and rrt_07 (400-iteration launches)
+    g = util.load_golden(util.GOLDEN + "/rrt04_c2_s1_it4000.npz")
+    kw = util.kwargs_from_golden(g)
+    h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
+                 kw["goal_sample_rate"], kw["max_iter"], robot_radius=kw["robot_radius"],
+                 connect_circle_dist=kw["connect_circle_dist"], search_until_max_iter=True, n_instances=1)
+    try:
+        h.set_obstacles(kw["obstacles"])
+        h.seed_instances([int(g["seed"])])
+        h.set_launch_bound(500)
+        h.plan_begin()
+        steps = 0
+        while True:
+            rc, n = h.plan_step()
+            steps += 1
+            if n == 0:
+                break
+        assert steps >= 9 and rc == 0
+        util.assert_tree_equal(h.get_tree(0), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+        assert np.array_equal(h.get_path(0), g["path"])
+    finally:
+        h.close()
+    g = util.load_golden(util.GOLDEN + "/rrt07_c3_sobol_s1_it3000.npz")
+    kw = util.informed_kwargs_from_golden(g)
+    c_min, c = rrt_amd.informed_rotation(kw["start"], kw["goal"])
+    h = A.Handle(A.ALGO_INFORMED, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], 1.0, kw["goal_sample_rate"],
+                 kw["max_iter"], sampler=A.SAMPLER_SOBOL, n_instances=1,
+                 informed_rot=[c[0, 0], c[0, 1], c[1, 0], c[1, 1]], informed_c_min=c_min)
+    try:
+        h.set_obstacles(kw["obstacles"])
+        h.seed_instances([int(g["seed"])])
+        h.set_launch_bound(400)
+        h.plan_begin()
+        steps = 0
+        while h.plan_step()[1]:
+            steps += 1
+        assert steps >= 7
+        util.assert_tree_equal(h.get_tree(0), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
+    finally:
+        h.close()
