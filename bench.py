@@ -221,9 +221,8 @@ class Workload:
         return h
 
     def step(self, h):
-        if self.a.workload == "c4":
-            h.seed_instances(self.seeds)   # BIT* handles keep their RNG position between plans
-        h.plan()                           # blocking: returns after the last kernel of the batch has finished
+        h.plan()                           # blocking: returns after the last kernel of the batch has finished; every plan
+                                           # starts from the staged per-instance state (seeds, starts, goals) again
 
     # -- report strings
     def names(self):
