@@ -1607,3 +1607,4 @@ def test_gpu_plan_in_bounded_steps(gpu):
         util.assert_tree_equal(h.get_tree(0), (g["x"], g["y"], g["cost"], g["parent"]), g["name"])
     finally:
         h.close()
+
