@@ -96,7 +96,13 @@ class NodeList:
         steer(nearest -> sample, expand_dis) (:1051);
       * appended under a chosen parent: steer(parent -> extension end, inf) (:1279).
     `creation` = (nearest index, sample x, sample y, kind) per node, from the device's per-iteration trace
-    (rrtx_get_trace / rrtx_get_trace_kind); without it every node falls back to steer(parent -> node, inf)."""
+    (rrtx_get_trace / rrtx_get_trace_kind); without it every node falls back to steer(parent -> node, inf).
+
+    Limit (draw-only data): the polylines are rebuilt from the FINAL coordinates of the nearest / parent node.  When a
+    later rewire moved that node (an unsnapped steer with an inexact path_resolution, rrt_04:1372), the reference's stored
+    polyline still starts at the old position, and a rewired node's path ends at the pre-move target; path_x / path_y are
+    exact only while no nearest node or ancestor has moved (with a binary-fraction resolution such as the C2 map's 0.25 none
+    moves).  Tree, costs and the returned path are not affected."""
 
     def __init__(self, x, y, cost, parent, res, expand_dis=None, creation=None):
         self._x, self._y, self._cost, self._parent, self._res = x, y, cost, parent, res

@@ -3,38 +3,38 @@
 # (the box has no .git: the hash of the commit being measured is handed in; do not edit the tree while the call is queued --
 # the snapshot is taken when the call starts)
 #   1. rocprofv3 passes of the headline bench: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)
-#      -> profiles/r2_c2_kernel_stats.csv, r2_c2_pmc_*.csv, r2_c2_traffic.json (device-code hash + commit inside)
-#   2. the driver's exact bench command under its 600 s limit -> r2_bench_c2_driver_cmd.json (reads the traffic file of 1.)
-#   3. per-phase split of the C2 iteration (diagnostic build) -> r2_c2_phase_4096x105k.txt; the same for the rrt_07 / rrt_05 kernels
+#      -> profiles/r3_c2_kernel_stats.csv, r3_c2_pmc_*.csv, r3_c2_traffic.json (device-code hash + commit inside)
+#   2. the driver's exact bench command under its 600 s limit -> r3_bench_c2_driver_cmd.json (reads the traffic file of 1.)
+#   3. per-phase split of the C2 iteration (diagnostic build) -> r3_c2_phase_4096x105k.txt; the same for the rrt_07 / rrt_05 kernels
 #      (needs robotics-path-planning_amd/librrtx_prof.so: `make -C robotics-path-planning_amd/csrc prof`, and tools/ubench/lat_ubench)
-#   4. C3..C6: bench line + VALU PMC pass -> r2_bench_<w>.json, r2_<w>_valu.json
-# Everything is written under gpurun_out/r2/ (merged back by gpurun); copy it into profiles/ and commit.
+#   4. C3..C6: bench line + VALU PMC pass -> r3_bench_<w>.json, r3_<w>_valu.json
+# Everything is written under gpurun_out/r3/ (merged back by gpurun); copy it into profiles/ and commit.
 export RRTX_COMMIT=${RRTX_COMMIT:-unknown}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-O=$REPO/gpurun_out/r2
+O=$REPO/gpurun_out/r3
 mkdir -p $O
 cd $REPO
-SUMMARY_ARGS="--workload c2" bash tools/profile_headline.sh r2_c2 > $O/profile_headline.log 2>&1
-cp profiles/r2_c2_* $O/ 2>/dev/null
+SUMMARY_ARGS="--workload c2" bash tools/profile_headline.sh r3_c2 > $O/profile_headline.log 2>&1
+cp profiles/r3_c2_* $O/ 2>/dev/null
 tail -2 $O/profile_headline.log
-timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r2_bench_c2_driver_cmd.json 2> $O/bench_driver.err
+timeout -k 10 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/r3_bench_c2_driver_cmd.json 2> $O/bench_driver.err
 echo "driver bench rc=$?"
-RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile.py 4096 105000 > $O/r2_c2_phase_4096x105k.txt 2>&1
+RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile.py 4096 105000 > $O/r3_c2_phase_4096x105k.txt 2>&1
 echo "phase rc=$?"
-RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c3.py 1024 20000 > $O/r2_c3_phase.txt 2>&1
-RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c5.py 1536 5000 > $O/r2_c5_phase.txt 2>&1
+RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c3.py 1024 20000 > $O/r3_c3_phase.txt 2>&1
+RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c5.py 1536 5000 > $O/r3_c5_phase.txt 2>&1
 echo "phase c3/c5 rc=$?"
 for w in c3 c4 c5 c6; do
   bash tools/valu_pass.sh $w > $O/valu_$w.log 2>&1
-  cp gpurun_out/r2_${w}_valu.json $O/ 2>/dev/null
-  cp gpurun_out/r2_${w}_valu.json profiles/ 2>/dev/null
-  timeout -k 10 150 python3 bench.py --workload $w --warmup 1 --steps 5 > $O/r2_bench_$w.json 2> $O/bench_$w.err
+  cp gpurun_out/r3_${w}_valu.json $O/ 2>/dev/null
+  cp gpurun_out/r3_${w}_valu.json profiles/ 2>/dev/null
+  timeout -k 10 150 python3 bench.py --workload $w --warmup 1 --steps 5 > $O/r3_bench_$w.json 2> $O/bench_$w.err
   echo "bench $w rc=$?"
 done
-timeout -k 10 120 tools/ubench/lat_ubench > $O/r2_lat_ubench.txt 2>&1
+timeout -k 10 120 tools/ubench/lat_ubench > $O/r3_lat_ubench.txt 2>&1
 python3 - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r2/r2_bench_*.json")):
+for f in sorted(glob.glob("gpurun_out/r3/r3_bench_*.json")):
     try:
         j = json.loads(open(f).read().strip().splitlines()[-1]); r = j["roofline"]
         print(f.split("/")[-1], "steps", j["steps"], "ms/step %.1f" % j["ms_per_step"], "value %.4g" % j["value"],

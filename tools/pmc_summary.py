@@ -85,7 +85,7 @@ if fs and wsz:
         tj["algorithmic_bytes_per_step"] = a.alg_bytes
         tj["traffic_over_algorithmic"] = (rd + wr) / a.alg_bytes
     out = os.path.join(prof, "%s_traffic.json" % a.tag)
-    if a.tag.startswith("r2_"):
-        out = os.path.join(prof, "r2_%s_traffic.json" % a.workload)
+    if a.tag[:1] == "r" and a.tag[1:2].isdigit() and a.tag[2:3] == "_":
+        out = os.path.join(prof, "%s_%s_traffic.json" % (a.tag[:2], a.workload))
     json.dump(tj, open(out, "w"), indent=1)
     print("wrote", out, json.dumps(tj))

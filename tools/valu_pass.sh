@@ -1,6 +1,6 @@
 #!/bin/bash
 # VALU-side roofline of a workload whose kernel is f64-VALU / latency bound (C3..C6): one rocprofv3 --pmc pass
-# (counters only) of `bench.py --workload <w>`; writes profiles/r2_<w>_valu.json (read back by bench.py as roofline.valu).
+# (counters only) of `bench.py --workload <w>`; writes profiles/r3_<w>_valu.json (read back by bench.py as roofline.valu).
 #   RRTX_COMMIT=$(git rev-parse --short HEAD) gpurun -- 'bash tools/valu_pass.sh c5'
 W=$1; shift
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -40,8 +40,8 @@ res = {"workload": w, "kernel": kern, "dispatches": d[(kern, "SQ_INSTS_VALU")], 
                         "1024 SIMDs): the share of the chip's VALU issue slots this kernel fills; f64_flops_upper counts 64 lanes per "
                         "instruction (an upper bound: the kernels run many instructions on a few lanes, see active_lane_frac)",
        "csrc_hash": ch.csrc_hash(w), "commit": os.environ.get("RRTX_COMMIT", "unknown")}
-json.dump(res, open(os.path.join(repo, "profiles", "r2_%s_valu.json" % w), "w"), indent=1)
-json.dump(res, open(os.path.join(repo, "gpurun_out", "r2_%s_valu.json" % w), "w"), indent=1)
+json.dump(res, open(os.path.join(repo, "profiles", "r3_%s_valu.json" % w), "w"), indent=1)
+json.dump(res, open(os.path.join(repo, "gpurun_out", "r3_%s_valu.json" % w), "w"), indent=1)
 print(json.dumps({k: res[k] for k in ("kernel", "valu_busy_frac", "f64_flops_upper_TFLOPs", "active_lane_frac", "kernel_ms_profiled_run")}))
 PY
 find $OUT -name "*.db" -delete 2>/dev/null
