@@ -251,8 +251,7 @@ int rrtx_get_smoothed_path(rrtx_handle* h, int32_t instance, double* xy, int32_t
 
 /* parity harness: out[i] = op(a[i], b[i]) evaluated on the device.  op 0 math.hypot, 1 x**2, 2 sin, 3 cos, 4 atan2,
  * 5 steer end x (rrt_04:1086-1115), 6 sqrt, 7 a/b, 8 acos, 9 asin, 10 checksum of the Reeds-Shepp steer
- * (0,0,0) -> (a, b, a+b) (rrt_06:1426-1441, csrc/rpp_rs.h); 11 sin, 12 cos, 13 atan2 in their one-lane forms (table reads on
- * the scalar memory path, csrc/glibc235_fma_math_u.h) */
+ * (0,0,0) -> (a, b, a+b) (rrt_06:1426-1441, csrc/rpp_rs.h) */
 int rrtx_selftest_math(int32_t device, int32_t op, const double* a, const double* b, double* out, int64_t n);
 
 /* Run-time check of the arithmetic contract: "identical to the reference on this host" holds while

@@ -31,7 +31,6 @@
 #include <stdint.h>
 
 #include "rpp_core.h"
-#include "glibc235_fma_math_u.h"
 #include "rpp_rs.h"
 
 namespace rppk {
@@ -1409,16 +1408,6 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
 // parity harness for the arithmetic replicas (rrtx_selftest_math)
 __global__ void selftest_kernel(int op, const double* a, const double* b, double* o, int64_t n) {
   int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (op >= 11 && op <= 13) {
-    // the one-lane forms (glibc235_fma_math_u.h: table reads on the scalar path): lane 0 of every wave evaluates its wave's
-    // 64 arguments one after the other, the other lanes are idle -- the only way these functions may be called
-    if ((threadIdx.x & 63) != 0) return;
-    for (int k = 0; k < 64 && i + k < n; k++) {
-      const double u = a[i + k], v = b[i + k];
-      o[i + k] = op == 11 ? rpp_glibc_sin_u(u) : op == 12 ? rpp_glibc_cos_u(u) : rpp_glibc_atan2_u(u, v);
-    }
-    return;
-  }
   if (i >= n) return;
   double r = 0.0;
   switch (op) {
