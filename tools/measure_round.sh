@@ -27,7 +27,7 @@ RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 to
 RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c5.py 1536 5000 > $O/r3_c5_phase.txt 2>&1
 echo "phase c3/c5 rc=$?"
 # C3 (rrt_07): kernel stats + HBM traffic passes of its own (profiles/r3_c3_kernel_stats.csv, r3_c3_traffic.json)
-SUMMARY_ARGS="--workload c3" bash tools/profile_headline.sh r3_c3 --workload c3 > $O/profile_headline_c3.log 2>&1
+SUMMARY_ARGS="--workload c3 --kernel-match rrt_informed_kernel --instances 1024 --max-iter 20000 --obstacles 200 --variant q16_mirror" bash tools/profile_headline.sh r3_c3 --workload c3 > $O/profile_headline_c3.log 2>&1
 cp profiles/r3_c3_* $O/ 2>/dev/null
 tail -1 $O/profile_headline_c3.log
 # kernel stats of the other workloads (C4: the bounded BIT* launches; C5, C6)
