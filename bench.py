@@ -508,8 +508,12 @@ def main():
             # dominant kernel's HIP-event time on every rank (the job's clock is the max)
             per_rank = sharding.gather_floats(dist, [dt, state["kms_main"] / 1e3], cuda)
             tot_eu, tot_er, tot_it = sharding.reduce_sum_int(dist, [state["eu"], state["er"], state["iters"]], cuda)
-            all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda,
-                                                             device_table=None if a.dry_run else h)
+            if state.get("native_rccl"):
+                all_pc, all_nn, all_st = h.rccl_gather_results()
+                all_pc, all_nn, all_st = np.asarray(all_pc), np.asarray(all_nn, dtype=np.int64), np.asarray(all_st, dtype=np.int64)
+            else:
+                all_pc, all_nn, all_st = sharding.gather_results(dist, pc, nn, st, cuda,
+                                                                 device_table=None if a.dry_run else h)
         else:
             tmax, tot_eu, tot_er, tot_it = dt, state["eu"], state["er"], state["iters"]
             all_pc, all_nn, all_st = np.asarray(pc), np.asarray(nn), np.asarray(st)
@@ -743,6 +747,21 @@ def main():
     if hw is not h:
         hw.close()
 
+    # ---- optional: the result table gathered by the library's own RCCL all_gather (rrtx_rccl_*: no framework in the data
+    # path) instead of torch.distributed's; rank 0's ncclUniqueId travels over the process group that is up anyway.  Off by
+    # default (the torch path is the one rehearsed at N > 1); any failure falls back to it.
+    native_rccl = False
+    if (os.environ.get("RRTX_BENCH_NATIVE_RCCL") and dist is not None and cuda is not None and not a.dry_run):
+        try:
+            box = [rrt_amd._abi.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            h.rccl_init(box[0], rank, ngpu)
+            native_rccl = True
+        except Exception as e:  # noqa: BLE001
+            print("bench.py rank %d: native RCCL gather unavailable (%s: %s), using torch.distributed" %
+                  (rank, type(e).__name__, e), file=sys.stderr, flush=True)
+        native_rccl = bool(sharding.all_agree_min(dist, 1 if native_rccl else 0, cuda))
+
     # ---- timed region
     sync_all()
     state["t0"] = time.perf_counter()
@@ -771,9 +790,12 @@ def main():
     state["dt"] = time.perf_counter() - state["t0"]
     state["warmup_done"] = warm_done
 
+    state["native_rccl"] = native_rccl
     line = build_line(h, final=True)
     if rank == 0:
         line["warmup"] = warm_done
+        line["result_gather"] = ("rrtx_rccl_gather_results (ncclAllGather from librrtx.so)" if native_rccl else
+                                 ("torch.distributed all_gather" if dist is not None else "single process"))
         state["printed"] = True
         print(json.dumps(line), flush=True)
     h.close()

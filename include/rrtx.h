@@ -28,7 +28,7 @@ extern "C" {
 #define RRTX_ABI_VERSION 4   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
                                 rrtx_copy_results_device, per-instance yaw and informed rotation; 4: rrtx_plan_many,
                                 rrtx_selfcheck, rrtx_stats.main_shape / main_f32, rrtx_plan_begin / _step, rrtx_set_launch_bound,
-                                RRTX_ST_REF_HANGS */
+                                RRTX_ST_REF_HANGS, rrtx_rccl_* */
 
 enum {
   RRTX_PARTIAL = 1,        /* rrtx_plan only: the call completed, but at least one instance stopped with RRTX_ST_OVERFLOW,
@@ -186,6 +186,15 @@ int rrtx_set_launch_bound(rrtx_handle* h, int32_t iterations);
  * batch over handles changes no result: instance j of handle i is the instance it would be in one large handle with the
  * same seed / start / goal.  The handles must be distinct. */
 int rrtx_plan_many(rrtx_handle** handles, int32_t n, int32_t* rcs);
+/* Multi-GPU with one process per GPU, without any host framework: the ONE collective of the path -- an ncclAllGather of the
+ * 16-byte result records {f64 path_cost, i32 n_nodes, i32 status}, device to device over RCCL / xGMI.  RCCL is
+ * opened with dlopen at first use (librrtx.so does not link it).  rank 0 calls rrtx_rccl_unique_id and hands the 128 bytes to
+ * the other ranks by the host's own means (a file, MPI, a torch store); every rank calls rrtx_rccl_init on its handle (same
+ * n_instances on every rank), plans, then rrtx_rccl_gather_results: world * n_instances entries, rank-major -- the table
+ * rrtx_get_results gives for one rank, for all of them.  No reference counterpart (the reference is one process). */
+int rrtx_rccl_unique_id(void* id128);
+int rrtx_rccl_init(rrtx_handle* h, const void* id128, int32_t rank, int32_t world);
+int rrtx_rccl_gather_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status);
 /* rrt.node_list as SoA: x, y, cost (f64), parent (i32, -1 = None); any pointer may be NULL. */
 int rrtx_get_tree(rrtx_handle* h, int32_t instance, double* x, double* y, double* cost, int32_t* parent,
                   int32_t cap, int32_t* n_out);

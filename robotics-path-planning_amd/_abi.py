@@ -26,7 +26,7 @@ EXPORTS = ["rrtx_abi_version", "rrtx_device_count", "rrtx_create", "rrtx_set_obs
            "rrtx_get_path", "rrtx_get_results", "rrtx_results_device_ptr", "rrtx_copy_results_device", "rrtx_get_sobol_index", "rrtx_get_yaw", "rrtx_get_polylines", "rrtx_get_stats",
            "rrtx_enable_trace", "rrtx_get_trace", "rrtx_get_trace_kind", "rrtx_get_phase_cycles", "rrtx_last_error", "rrtx_destroy", "rrtx_selftest_math",
            "rrtx_smooth_paths", "rrtx_smooth_planned", "rrtx_get_smoothed_path", "rrtx_get_path_yaw", "rrtx_selfcheck", "rrtx_plan_many", "rrtx_plan_begin", "rrtx_plan_step",
-           "rrtx_set_launch_bound"]
+           "rrtx_set_launch_bound", "rrtx_rccl_unique_id", "rrtx_rccl_init", "rrtx_rccl_gather_results"]
 
 
 class Params(C.Structure):
@@ -108,6 +108,9 @@ def load():
     L.rrtx_plan_begin.argtypes = [vp]
     L.rrtx_plan_step.argtypes = [vp, C.POINTER(i32)]
     L.rrtx_set_launch_bound.argtypes = [vp, i32]
+    L.rrtx_rccl_unique_id.argtypes = [vp]
+    L.rrtx_rccl_init.argtypes = [vp, vp, i32, i32]
+    L.rrtx_rccl_gather_results.argtypes = [vp, vp, vp, vp]
     for f in EXPORTS:
         if f not in ("rrtx_last_error", "rrtx_destroy", "rrtx_abi_version", "rrtx_device_count"):
             getattr(L, f).restype = C.c_int
@@ -285,6 +288,20 @@ class Handle:
         self._chk(rc, "rrtx_plan_step")
         return rc, n.value
 
+    def rccl_init(self, unique_id, rank, world):
+        """Join the RCCL communicator of a multi-process run (unique_id: the 128 bytes of `rccl_unique_id()` made by rank 0)."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+        self._chk(self.L.rrtx_rccl_init(self._h, C.cast(buf, C.c_void_p), int(rank), int(world)), "rrtx_rccl_init")
+        self._rccl_world = int(world)
+
+    def rccl_gather_results(self):
+        """(path_cost, n_nodes, status) of ALL ranks, rank-major: one ncclAllGather of the 16-byte records, device to device."""
+        n = self.n_instances * self._rccl_world
+        pc = np.zeros(n); nn = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+        self._chk(self.L.rrtx_rccl_gather_results(self._h, pc.ctypes.data, nn.ctypes.data, st.ctypes.data),
+                  "rrtx_rccl_gather_results")
+        return pc, nn, st
+
     def last_error(self):
         return self.L.rrtx_last_error(self._h).decode()
 
@@ -394,6 +411,16 @@ class Handle:
         kind = np.zeros(cap, dtype=np.int32)
         self._chk(self.L.rrtx_get_trace_kind(self._h, kind.ctypes.data, cap, C.byref(n)), "rrtx_get_trace_kind")
         return kind[:n.value]
+
+
+def rccl_unique_id():
+    """The 128-byte ncclUniqueId of a new communicator (rank 0 makes it and hands it to the other ranks)."""
+    L = load()
+    buf = (C.c_char * 128)()
+    rc = L.rrtx_rccl_unique_id(C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise RrtxError("rrtx_rccl_unique_id: %s (librccl.so not loadable?)" % ERRORS.get(rc, rc))
+    return bytes(buf)
 
 
 def plan_many(handles, strict=False):

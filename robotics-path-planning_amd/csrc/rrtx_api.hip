@@ -3,6 +3,8 @@
 // kernel in bounded chunks of iterations on the handle's HIP stream, and copies
 // results back.  There is no CPU planning path in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym at first use (no link-time dependency)
 
 #include <algorithm>
 #include <chrono>
@@ -48,6 +50,41 @@ inline double py_sq_host(double x) {
 
 }  // namespace
 
+// RCCL, opened with dlopen at first use (rrtx_rccl_*): no link-time dependency, nothing loaded by single-GPU users
+namespace {
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+RcclApi* rccl_api() {
+  static RcclApi api;
+  if (api.lib || !api.err.empty()) return &api;
+  for (const char* nm : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) {
+    api.err = std::string("librccl.so not loadable: ") + (dlerror() ? dlerror() : "?");
+    return &api;
+  }
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+  api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) {
+    api.err = "librccl.so lacks ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclCommDestroy";
+    api.lib = nullptr;
+  }
+  return &api;
+}
+}  // namespace
+
 struct rrtx_handle {
   rrtx_params p;
   int device = 0;
@@ -78,6 +115,10 @@ struct rrtx_handle {
   } run;
   int32_t *bit_queue = nullptr, *bit_qhead = nullptr;   // BIT*: device copy of `pending`, queue head counter
   int bit_trip_bound = 20000;    // BIT*: trips of plan()'s loop per instance and launch (rrt_bitstar_wave.hip.h)
+  // native RCCL gather of the result table (rrtx_rccl_*): communicator of this rank, world size, receive buffer
+  void* rccl_comm = nullptr;
+  int rccl_world = 0, rccl_rank = 0;
+  Result* rccl_recv = nullptr;
   int chunk_iters = 32768;       // iterations per launch of the other planner kernels
   int32_t* inst_map = nullptr;   // device: instance ids of a partial re-plan (overflow retry)
   // pose planners: where an instance's edge polylines live -- the handle's pool (slab = instance), or a larger pool
@@ -209,6 +250,10 @@ const char* rrtx_last_error(rrtx_handle* h) { return h ? h->err.c_str() : "null 
 void rrtx_destroy(rrtx_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
+  if (h->rccl_comm) {
+    RcclApi* a = rccl_api();
+    if (a->lib) a->CommDestroy((ncclComm_t)h->rccl_comm);
+  }
   for (void* q : h->allocs) hipFree(q);
   for (auto& bp : h->big) {
     if (bp.px) hipFree(bp.px);
@@ -1584,6 +1629,72 @@ int rrtx_selfcheck(int32_t device, int32_t n_per_fn, int64_t* mismatches8) {
       if (memcmp(&r, &out[i], 8) != 0) bad++;
     }
     mismatches8[f] = bad;
+  }
+  return RRTX_OK;
+}
+
+// ---- native RCCL: the one collective of the path (ncclAllGather of the 16-byte result records over xGMI) ----------
+
+int rrtx_rccl_unique_id(void* id128) {
+  if (!id128) return RRTX_E_INVALID;
+  RcclApi* a = rccl_api();
+  if (!a->lib) return RRTX_E_STATE;
+  ncclUniqueId id;
+  if (a->GetUniqueId(&id) != ncclSuccess) return RRTX_E_HIP;
+  memcpy(id128, &id, sizeof(id));
+  return RRTX_OK;
+}
+
+int rrtx_rccl_init(rrtx_handle* h, const void* id128, int32_t rank, int32_t world) {
+  if (!h || !id128 || world < 1 || rank < 0 || rank >= world) return RRTX_E_INVALID;
+  RcclApi* a = rccl_api();
+  if (!a->lib) {
+    h->err = a->err;
+    return RRTX_E_STATE;
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->rccl_comm) {
+    a->CommDestroy((ncclComm_t)h->rccl_comm);
+    h->rccl_comm = nullptr;
+  }
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = a->CommInitRank(&comm, world, id, rank);
+  if (r != ncclSuccess) {
+    h->err = std::string("ncclCommInitRank: ") + (a->GetErrorString ? a->GetErrorString(r) : "error");
+    return RRTX_E_HIP;
+  }
+  h->rccl_comm = (void*)comm;
+  h->rccl_world = world;
+  h->rccl_rank = rank;
+  if (!h->rccl_recv) {
+    int rc = dalloc(h, &h->rccl_recv, (size_t)h->n_inst * world);
+    if (rc) return rc;
+  }
+  return RRTX_OK;
+}
+
+int rrtx_rccl_gather_results(rrtx_handle* h, double* path_cost, int32_t* n_nodes, int32_t* status) {
+  if (!h) return RRTX_E_INVALID;
+  if (!h->planned || !h->rccl_comm) return RRTX_E_STATE;
+  RcclApi* a = rccl_api();
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t bytes = sizeof(Result) * (size_t)h->n_inst;
+  // device -> device: the table the planner kernels wrote is what the collective sends
+  const ncclResult_t r = a->AllGather(h->c.results, h->rccl_recv, bytes, ncclInt8, (ncclComm_t)h->rccl_comm, h->stream);
+  if (r != ncclSuccess) {
+    h->err = std::string("ncclAllGather: ") + (a->GetErrorString ? a->GetErrorString(r) : "error");
+    return RRTX_E_HIP;
+  }
+  const size_t tot = (size_t)h->n_inst * h->rccl_world;
+  std::vector<Result> all(tot);
+  HIPCHK(h, hipMemcpyAsync(all.data(), h->rccl_recv, sizeof(Result) * tot, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < tot; i++) {
+    if (path_cost) path_cost[i] = (all[i].status & RRTX_ST_PATH) ? all[i].path_cost : INFINITY;
+    if (n_nodes) n_nodes[i] = all[i].n_nodes;
+    if (status) status[i] = all[i].status;
   }
   return RRTX_OK;
 }

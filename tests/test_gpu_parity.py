@@ -1608,3 +1608,48 @@ def test_gpu_plan_in_bounded_steps(gpu):
     finally:
         h.close()
 
+
+
+@pytest.mark.gpu
+def test_native_rccl_gather_of_the_result_table(gpu):
+    """rrtx_rccl_unique_id / rrtx_rccl_init / rrtx_rccl_gather_results: the path's one collective as a native ncclAllGather
+    (RCCL opened with dlopen by librrtx.so, no framework in between).  The builder's box has one GPU: world size 1 -- the
+    gathered table must be the handle's own result table; and bench.py's opt-in use of it (RRTX_BENCH_NATIVE_RCCL=1 with
+    a forced world-size-1 process group) prints the same line as the torch.distributed gather."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import rrt_amd
+    A = rrt_amd._abi
+    kw = util.c2_kwargs(1200)
+    h = A.Handle(A.ALGO_RRT_STAR, kw["start"], kw["goal"], kw["rand_area"], kw["expand_dis"], kw["path_resolution"],
+                 kw["goal_sample_rate"], kw["max_iter"], robot_radius=0.0, connect_circle_dist=50.0,
+                 search_until_max_iter=True, n_instances=24)
+    try:
+        h.set_obstacles(kw["obstacles"])
+        h.seed_instances(list(range(1, 25)))
+        uid = A.rccl_unique_id()
+        assert len(uid) == 128
+        h.rccl_init(uid, 0, 1)
+        h.plan()
+        pc, nn, st = h.get_results()
+        gpc, gnn, gst = h.rccl_gather_results()
+        assert np.array_equal(pc, gpc) and np.array_equal(nn, gnn) and np.array_equal(st, gst)
+    finally:
+        h.close()
+    env = dict(os.environ, RRTX_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29517", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    lines = []
+    for native in ("", "1"):
+        e = dict(env)
+        if native:
+            e["RRTX_BENCH_NATIVE_RCCL"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--instances", "48", "--max-iter", "1500",
+                            "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=e,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    assert lines[1]["result_gather"].startswith("rrtx_rccl_gather_results") and lines[0]["result_gather"].startswith("torch")
+    for k in ("paths_found", "final_path_cost_mean", "final_path_cost_min", "mean_nodes_per_tree", "instances_total"):
+        assert lines[0][k] == lines[1][k], k
