@@ -102,6 +102,40 @@ __device__ __forceinline__ void w_erase(T* a, int ri, int n) {
 // Inst status), where a wave picks it up again; the host re-queues what is not done (rrtx_api.hip).
 constexpr int ST_CARRY = 0x100;   // Inst::status only (never in a result record): state stored, to be resumed
 
+// edge_queue.remove: the five columns of the edge queue shifted together (one load / store round per 256 entries instead
+// of five)
+__device__ __forceinline__ void w_erase_edge(double* a, double* b, int32_t* ai, double* dab, double* hb, int ri, int n) {
+  const int lane = threadIdx.x;
+  for (int base = ri; base + 1 < n; base += 256) {
+    double ta[4], tb[4], td[4], th[4];
+    int32_t ti[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + u * 64 + lane;
+      if (j + 1 < n) {
+        ta[u] = a[j + 1];
+        tb[u] = b[j + 1];
+        ti[u] = ai[j + 1];
+        td[u] = dab[j + 1];
+        th[u] = hb[j + 1];
+      }
+    }
+    wsync();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + u * 64 + lane;
+      if (j + 1 < n) {
+        a[j] = ta[u];
+        b[j] = tb[u];
+        ai[j] = ti[u];
+        dab[j] = td[u];
+        hb[j] = th[u];
+      }
+    }
+    wsync();
+  }
+}
+
 __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst* inst, rppk::Result* results,
                                                           int n_inst) {
   __shared__ ShB sh;
@@ -351,12 +385,30 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
       if (neq) {
         double mx = -inf, mn = inf;
         int mi = 0x7fffffff;
-        for (int j = lane; j < neq; j += 64) {
-          const double val = sh.vg[eq_ai[j]] + eq_dab[j] + eq_hb[j];
-          mx = val > mx ? val : mx;   // values.sort(reverse=True)[0]: the MAXIMUM (:452-453)
-          if (val < mn) {
-            mn = val;
-            mi = j;
+        // four queue entries per lane and round trip (12 independent loads in flight): with thousands of queued edges this
+        // scan, once per popped edge and per expanded vertex, is what the slowest instances of a batch spend their time in
+        for (int j0 = lane; j0 < neq; j0 += 256) {
+          int ai[4];
+          double da[4], hb[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int j = j0 + 64 * u;
+            const int jj = j < neq ? j : j0;   // in range: the value is not used
+            ai[u] = eq_ai[jj];
+            da[u] = eq_dab[jj];
+            hb[u] = eq_hb[jj];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int j = j0 + 64 * u;
+            if (j < neq) {
+              const double val = sh.vg[ai[u]] + da[u] + hb[u];
+              mx = val > mx ? val : mx;   // values.sort(reverse=True)[0]: the MAXIMUM (:452-453)
+              if (val < mn) {
+                mn = val;
+                mi = j;
+              }
+            }
           }
         }
         be = w_max(mx);
@@ -379,13 +431,27 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
       const double d_sv = rpp::bit_dist(c, start_id, vid);
       double cx, cy;
       rpp::bit_coord(c, vid, &cx, &cy);
-      for (int base = 0; base < ns; base += 64) {   // samples.items() in dict order; RAW sample coordinates (:485-488)
+      for (int base0 = 0; base0 < ns && !fail; base0 += 256) {   // samples.items() in dict order; RAW sample coordinates (:485-488)
+       // four chunks of 64 samples requested together, appended chunk by chunk in order
+       double p_id[4], p_x[4], p_y[4];
+#pragma unroll
+       for (int u = 0; u < 4; u++) {
+         const int k = base0 + 64 * u + lane;
+         const int kk = k < ns ? k : 0;
+         p_id[u] = sid[kk];
+         p_x[u] = sx[kk];
+         p_y[u] = sy[kk];
+       }
+#pragma unroll
+       for (int u = 0; u < 4; u++) {
+        const int base = base0 + 64 * u;
+        if (base >= ns || fail) continue;
         const int k = base + lane;
         bool pred = false;
         double sidk = 0.0, d_sg = 0.0, d_vs = 0.0;
         if (k < ns) {
-          sidk = sid[k];
-          if (rpp::bit_norm(sx[k] - cx, sy[k] - cy) <= 2.0 && sidk != vid) {
+          sidk = p_id[u];
+          if (rpp::bit_norm(p_x[u] - cx, p_y[u] - cy) <= 2.0 && sidk != vid) {
             d_sg = rpp::bit_dist(c, sidk, goal_id);
             d_vs = rpp::bit_dist(c, vid, sidk);
             const double est = d_sv + d_sg + d_vs;
@@ -398,7 +464,7 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
           if (neq + add > EC) {
             error = 2;
             fail = true;
-            break;
+            continue;
           }
           if (pred) {
             const int pos = neq + __popcll(m & below);
@@ -410,6 +476,7 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
           }
           neq += add;
         }
+       }
       }
       wsync();
       if (fail) break;
@@ -433,11 +500,7 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
       int ri = w_find_pair(eq_a, eq_b, neq, ea, eb);
       if (ri < 0) ri = 0;
       wsync();
-      w_erase(eq_a, ri, neq);
-      w_erase(eq_b, ri, neq);
-      w_erase(eq_ai, ri, neq);
-      w_erase(eq_dab, ri, neq);
-      w_erase(eq_hb, ri, neq);
+      w_erase_edge(eq_a, eq_b, eq_ai, eq_dab, eq_hb, ri, neq);
       neq--;
     }
     const int v0 = ea_i;
@@ -594,11 +657,7 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
           const int ri = w_find_pair(eq_a, eq_b, neq, last_edge, next_id);
           if (ri >= 0) {
             wsync();
-            w_erase(eq_a, ri, neq);
-            w_erase(eq_b, ri, neq);
-            w_erase(eq_ai, ri, neq);
-            w_erase(eq_dab, ri, neq);
-            w_erase(eq_hb, ri, neq);
+            w_erase_edge(eq_a, eq_b, eq_ai, eq_dab, eq_hb, ri, neq);
             neq--;
           }
         }
