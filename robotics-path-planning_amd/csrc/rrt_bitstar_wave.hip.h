@@ -53,24 +53,71 @@ __device__ __forceinline__ double w_max(double v) {
   return v;
 }
 // first j in [from, n) with a[j] == key, else -1 (wave-uniform result)
+// (four chunks of 64 entries are requested together and examined in order: one round trip per 256 entries)
 template <class T>
 __device__ __forceinline__ int w_find(const T* a, int from, int n, T key) {
   const int lane = threadIdx.x;
-  for (int base = from; base < n; base += 64) {
-    const int j = base + lane;
-    const uint64_t m = __ballot(j < n && a[j] == key);
-    if (m) return base + __ffsll((long long)m) - 1;
+  for (int base = from; base < n; base += 256) {
+    T v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + 64 * u + lane;
+      v[u] = a[j < n ? j : from];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + 64 * u + lane;
+      const uint64_t m = __ballot(j < n && v[u] == key);
+      if (m) return base + 64 * u + __ffsll((long long)m) - 1;
+    }
   }
   return -1;
 }
 __device__ __forceinline__ int w_find_pair(const double* a, const double* b, int n, double ka, double kb) {
   const int lane = threadIdx.x;
-  for (int base = 0; base < n; base += 64) {
-    const int j = base + lane;
-    const uint64_t m = __ballot(j < n && a[j] == ka && b[j] == kb);
-    if (m) return base + __ffsll((long long)m) - 1;
+  for (int base = 0; base < n; base += 256) {
+    double va[4], vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + 64 * u + lane;
+      va[u] = a[j < n ? j : 0];
+      vb[u] = b[j < n ? j : 0];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + 64 * u + lane;
+      const uint64_t m = __ballot(j < n && va[u] == ka && vb[u] == kb);
+      if (m) return base + 64 * u + __ffsll((long long)m) - 1;
+    }
   }
   return -1;
+}
+// del self.samples[id]: the three sample columns shifted together
+__device__ __forceinline__ void w_erase3(double* a, double* b, double* c3, int ri, int n) {
+  const int lane = threadIdx.x;
+  for (int base = ri; base + 1 < n; base += 256) {
+    double ta[4], tb[4], tc[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + u * 64 + lane;
+      if (j + 1 < n) {
+        ta[u] = a[j + 1];
+        tb[u] = b[j + 1];
+        tc[u] = c3[j + 1];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = base + u * 64 + lane;
+      if (j + 1 < n) {
+        a[j] = ta[u];
+        b[j] = tb[u];
+        c3[j] = tc[u];
+      }
+    }
+    __syncthreads();
+  }
 }
 // list.remove at position ri of an array of length n (order preserving)
 template <class T>
@@ -551,9 +598,7 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
         const int di = w_find(sid, 0, ns, next_id);
         if (di >= 0) {
           wsync();
-          w_erase(sid, di, ns);
-          w_erase(sx, di, ns);
-          w_erase(sy, di, ns);
+          w_erase3(sid, sx, sy, di, ns);
           ns--;
         }
       }
