@@ -149,15 +149,19 @@ __device__ __forceinline__ void w_erase(T* a, int ri, int n) {
 // Inst status), where a wave picks it up again; the host re-queues what is not done (rrtx_api.hip).
 constexpr int ST_CARRY = 0x100;   // Inst::status only (never in a result record): state stored, to be resumed
 
-// edge_queue.remove: the five columns of the edge queue shifted together (one load / store round per 256 entries instead
-// of five)
+#ifndef RRTX_BIT_EW
+#define RRTX_BIT_EW 8
+#endif
+constexpr int EW = RRTX_BIT_EW;   // edge-queue entries per lane and round trip (scan, shift)
+// edge_queue.remove: the five columns of the edge queue shifted together (one load / store round per 64 EW entries instead
+// of five per 256)
 __device__ __forceinline__ void w_erase_edge(double* a, double* b, int32_t* ai, double* dab, double* hb, int ri, int n) {
   const int lane = threadIdx.x;
-  for (int base = ri; base + 1 < n; base += 256) {
-    double ta[4], tb[4], td[4], th[4];
-    int32_t ti[4];
+  for (int base = ri; base + 1 < n; base += 64 * EW) {
+    double ta[EW], tb[EW], td[EW], th[EW];
+    int32_t ti[EW];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < EW; u++) {
       const int j = base + u * 64 + lane;
       if (j + 1 < n) {
         ta[u] = a[j + 1];
@@ -169,7 +173,7 @@ __device__ __forceinline__ void w_erase_edge(double* a, double* b, int32_t* ai, 
     }
     wsync();
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < EW; u++) {
       const int j = base + u * 64 + lane;
       if (j + 1 < n) {
         a[j] = ta[u];
@@ -432,13 +436,13 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
       if (neq) {
         double mx = -inf, mn = inf;
         int mi = 0x7fffffff;
-        // four queue entries per lane and round trip (12 independent loads in flight): with thousands of queued edges this
+        // EW queue entries per lane and round trip (3 EW independent loads in flight): with thousands of queued edges this
         // scan, once per popped edge and per expanded vertex, is what the slowest instances of a batch spend their time in
-        for (int j0 = lane; j0 < neq; j0 += 256) {
-          int ai[4];
-          double da[4], hb[4];
+        for (int j0 = lane; j0 < neq; j0 += 64 * EW) {
+          int ai[EW];
+          double da[EW], hb[EW];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < EW; u++) {
             const int j = j0 + 64 * u;
             const int jj = j < neq ? j : j0;   // in range: the value is not used
             ai[u] = eq_ai[jj];
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(64) void bitstar_wave_kernel(BitArgs a, rppk::Inst*
             hb[u] = eq_hb[jj];
           }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < EW; u++) {
             const int j = j0 + 64 * u;
             if (j < neq) {
               const double val = sh.vg[ai[u]] + da[u] + hb[u];
