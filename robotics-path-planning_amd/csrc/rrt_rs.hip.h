@@ -322,10 +322,23 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     // The reference's distance is dx**2 + dy**2 with libm pow (rpp::py_d2); correctly rounded squares
     // (rpp::fast_d2) are within 2^-51 relative of it, so they decide everything except near-ties: the exact form is
     // evaluated only for nodes within FILTER_EPS of the fast minimum.
+    // (scans: four nodes per lane and round trip -- the coordinates of 256 nodes are requested together; a loop that waits
+    // for every pair of loads spends a memory round trip per 64 nodes)
     double fb = rpp::dinf();
-    for (int i = lane; i < n; i += TPB) {
-      const double f = rpp::fast_d2(x[i] - rx, y[i] - ry);
-      fb = f < fb ? f : fb;
+    for (int i0 = lane; i0 < n; i0 += 4 * TPB) {
+      double vx[4], vy[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * TPB;
+        const int ii = i < n ? i : i0;
+        vx[u] = x[ii];
+        vy[u] = y[ii];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double f = (i0 + u * TPB < n) ? rpp::fast_d2(vx[u] - rx, vy[u] - ry) : rpp::dinf();
+        fb = f < fb ? f : fb;
+      }
     }
     for (int o = 32; o >= 1; o >>= 1) {
       const double of = __shfl_xor(fb, o);
@@ -334,13 +347,25 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     const double fthr = fb * (1.0 + rppk::FILTER_EPS);
     double bd = rpp::dinf();
     int ni = 0x7fffffff;
-    for (int i = lane; i < n; i += TPB) {
-      const double dx = x[i] - rx, dy = y[i] - ry;
-      if (rpp::fast_d2(dx, dy) <= fthr) {
-        const double d = rpp::py_d2(dx, dy);
-        if (d < bd) {
-          bd = d;
-          ni = i;
+    for (int i0 = lane; i0 < n; i0 += 4 * TPB) {
+      double vx[4], vy[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * TPB;
+        const int ii = i < n ? i : i0;
+        vx[u] = x[ii];
+        vy[u] = y[ii];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * TPB;
+        const double dx = vx[u] - rx, dy = vy[u] - ry;
+        if (i < n && rpp::fast_d2(dx, dy) <= fthr) {
+          const double d = rpp::py_d2(dx, dy);
+          if (d < bd) {
+            bd = d;
+            ni = i;
+          }
         }
       }
     }
@@ -363,12 +388,23 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
       // stage 1: nodes whose fast distance is not clearly outside the ball, in index order (a superset of the hits)
       int kc = 0;
       const double r2hi = r2 * (1.0 + rppk::FILTER_EPS);
-      for (int base = 0; base < n; base += TPB) {
-        const int i = base + lane;
-        const bool maybe = i < n && rpp::fast_d2(x[i] - nx, y[i] - ny) <= r2hi;
-        const unsigned long long b = __ballot(maybe);
-        if (maybe) mark[kc + __popcll(b & ((1ULL << lane) - 1ULL))] = i;
-        kc += __popcll(b);
+      for (int base0 = 0; base0 < n; base0 += 4 * TPB) {
+        double vx[4], vy[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base0 + u * TPB + lane;
+          const int ii = i < n ? i : 0;
+          vx[u] = x[ii];
+          vy[u] = y[ii];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base0 + u * TPB + lane;
+          const bool maybe = i < n && rpp::fast_d2(vx[u] - nx, vy[u] - ny) <= r2hi;
+          const unsigned long long b = __ballot(maybe);
+          if (maybe) mark[kc + __popcll(b & ((1ULL << lane) - 1ULL))] = i;
+          kc += __popcll(b);
+        }
       }
       __syncthreads();
       // stage 2: the reference's own distance for those, the <= r**2 test on it, ordered compaction
