@@ -115,6 +115,9 @@ struct rrtx_handle {
   } run;
   int32_t *bit_queue = nullptr, *bit_qhead = nullptr;   // BIT*: device copy of `pending`, queue head counter
   int bit_trip_bound = 20000;    // BIT*: trips of plan()'s loop per instance and launch (rrt_bitstar_wave.hip.h)
+  Inst* d_inst0 = nullptr;       // device copy of host_inst (the staged start state of every instance)
+  bool inst_dirty = true;        // host_inst changed since d_inst0 was written
+  rppk::StatsAcc* d_acc = nullptr;
   // native RCCL gather of the result table (rrtx_rccl_*): communicator of this rank, world size, receive buffer
   void* rccl_comm = nullptr;
   int rccl_world = 0, rccl_rank = 0;
@@ -479,6 +482,7 @@ int rrtx_set_obstacles(rrtx_handle* h, const double* oxyr, int32_t m) {
 
 int rrtx_set_rng_state(rrtx_handle* h, int32_t instance, const uint32_t* mt624, int32_t pos) {
   if (!h || !mt624 || instance < 0 || instance >= h->n_inst || pos < 0 || pos > 624) return RRTX_E_INVALID;
+  h->inst_dirty = true;
   memcpy(h->host_inst[instance].rng.mt, mt624, 624 * 4);
   h->host_inst[instance].rng.pos = pos;
   return RRTX_OK;
@@ -501,12 +505,14 @@ int rrtx_get_rng_state(rrtx_handle* h, int32_t instance, uint32_t* mt624, int32_
 
 int rrtx_seed_instances(rrtx_handle* h, int32_t first, int32_t count, const uint64_t* seeds) {
   if (!h || !seeds || first < 0 || count < 0 || first + count > h->n_inst) return RRTX_E_INVALID;
+  h->inst_dirty = true;
   for (int i = 0; i < count; i++) rpp::mt_seed_u64(&h->host_inst[first + i].rng, seeds[i]);
   return RRTX_OK;
 }
 
 int rrtx_set_instance(rrtx_handle* h, int32_t instance, const double* start3, const double* goal3) {
   if (!h || instance < 0 || instance >= h->n_inst) return RRTX_E_INVALID;
+  h->inst_dirty = true;
   Inst& I = h->host_inst[instance];
   if (start3) {
     I.start[0] = start3[0];
@@ -625,7 +631,18 @@ int rrtx_plan_begin(rrtx_handle* h) {
     if (atoi(e) == 0 && c.algo == RRTX_ALGO_INFORMED) c.xf = c.yf = nullptr;   // informed kernel: f64 passes only
   if (const char* e = getenv("RRTX_Q16"))
     if (atoi(e) == 0) c.xq = nullptr;   // rrt_04 kernel: no 16-bit first stage (f32 mirror first)
-  HIPCHK(h, hipMemcpyAsync(c.inst, h->host_inst.data(), sizeof(Inst) * B, hipMemcpyHostToDevice, h->stream));
+  // The staged per-instance start state (RNG, start / goal) lives on the device too: uploaded when the host changed it,
+  // copied device -> device at every plan (2.7 KB per instance: 44 MB of pageable-memory upload per plan of 16 384 instances)
+  if (!h->d_inst0) {
+    int rc2 = dalloc(h, &h->d_inst0, B);
+    if (rc2) return rc2;
+    h->inst_dirty = true;
+  }
+  if (h->inst_dirty) {
+    HIPCHK(h, hipMemcpyAsync(h->d_inst0, h->host_inst.data(), sizeof(Inst) * B, hipMemcpyHostToDevice, h->stream));
+    h->inst_dirty = false;
+  }
+  HIPCHK(h, hipMemcpyAsync(c.inst, h->d_inst0, sizeof(Inst) * B, hipMemcpyDeviceToDevice, h->stream));
   {
     dim3 g(64, B);
     hipLaunchKernelGGL(rppk::rrt_init_kernel, g, dim3(256), 0, h->stream, c);
@@ -1054,34 +1071,37 @@ static int plan_finish(rrtx_handle* h) {
     }
   }
   // aggregate counters
-  std::vector<Inst> back(B);
-  HIPCHK(h, hipMemcpy(back.data(), c.inst, sizeof(Inst) * B, hipMemcpyDeviceToHost));
+  // summed on the device (rppk::stats_reduce_kernel): one small record comes back instead of every Inst
+  if (!h->d_acc) {
+    int rc2 = dalloc(h, &h->d_acc, 1);
+    if (rc2) return rc2;
+  }
+  rppk::StatsAcc acc;
+  HIPCHK(h, hipMemsetAsync(h->d_acc, 0, sizeof(rppk::StatsAcc), h->stream));
+  hipLaunchKernelGGL(rppk::stats_reduce_kernel, dim3((B + 255) / 256), dim3(256), 0, h->stream, c.inst, B, h->d_acc);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(&acc, h->d_acc, sizeof(acc), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   rrtx_stats& s = h->stats;
   memset(&s, 0, sizeof(s));
-  memset(h->phase, 0, sizeof(h->phase));
-  bool overflow = false, unsupported = false, raises = false;
-  for (int i = 0; i < B; i++) {
-    const Inst& I = back[i];
-    s.iterations += I.iterations;
-    s.edges_unique += I.edges_unique;
-    s.edges_ref += I.edges_ref;
-    s.near_hits += I.near_hits;
-    s.near_unique += I.near_unique;
-    s.rewires += I.rewires;
-    s.propagated += I.propagated;
-    s.scan_nodes += I.scan_nodes;
-    s.algorithmic_bytes += I.alg_bytes;
-    s.exact_rescans += I.exact_rescans;
-    s.algorithmic_bytes_two_scan += I.alg_bytes2;
-    s.total_nodes += I.n;
-    s.f32_fallbacks += I.f32_fallbacks;
-    s.q16_fallbacks += I.q16_fallbacks;
-    if (I.nu_max > s.near_unique_max) s.near_unique_max = I.nu_max;
-    if (I.status & RRTX_ST_OVERFLOW) overflow = true;
-    if (I.status & RRTX_ST_UNSUPPORTED) unsupported = true;
-    if (I.status & RRTX_ST_REF_RAISES) raises = true;
-    for (int k = 0; k < 16; k++) h->phase[k] += I.phase[k];
-  }
+  s.iterations = acc.sum[0];
+  s.edges_unique = acc.sum[1];
+  s.edges_ref = acc.sum[2];
+  s.near_hits = acc.sum[3];
+  s.near_unique = acc.sum[4];
+  s.rewires = acc.sum[5];
+  s.propagated = acc.sum[6];
+  s.scan_nodes = acc.sum[7];
+  s.algorithmic_bytes = acc.sum[8];
+  s.exact_rescans = acc.sum[9];
+  s.algorithmic_bytes_two_scan = acc.sum[10];
+  s.total_nodes = acc.sum[11];
+  s.f32_fallbacks = acc.sum[12];
+  s.q16_fallbacks = acc.sum[13];
+  s.near_unique_max = acc.nu_max;
+  for (int k = 0; k < 16; k++) h->phase[k] = acc.phase[k];
+  const bool overflow = (acc.status_or & RRTX_ST_OVERFLOW) != 0, unsupported = (acc.status_or & RRTX_ST_UNSUPPORTED) != 0,
+             raises = (acc.status_or & RRTX_ST_REF_RAISES) != 0;
   s.launches = launches;
   s.kernel_ms = kms;
   s.launches_main = kms_main >= 0.0 ? launches_main : launches;
