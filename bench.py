@@ -638,7 +638,7 @@ def main():
                           "makes them for the same trees (repeated near indices included, SURVEY R6)",
         }
         ls = state["last_stats"]
-        for k in ("near_unique_max", "f32_fallbacks", "q16_fallbacks", "exact_rescans"):
+        for k in ("near_unique_max", "f32_fallbacks", "q16_fallbacks", "exact_rescans", "passes_shared"):
             if k in ls:
                 line[k + "_last_step"] = ls[k]
         if a.workload in ("c5", "c6"):

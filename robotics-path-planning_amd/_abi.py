@@ -51,7 +51,7 @@ class Stats(C.Structure):
                 ("kernel_ms", C.c_double), ("plan_ms", C.c_double), ("algorithmic_bytes_two_scan", C.c_int64),
                 ("near_unique_max", C.c_int64), ("f32_fallbacks", C.c_int64), ("q16_fallbacks", C.c_int64),
                 ("launches_main", C.c_int64), ("kernel_ms_main", C.c_double), ("replanned", C.c_int64),
-                ("main_shape", C.c_int32), ("main_f32", C.c_int32)]
+                ("main_shape", C.c_int32), ("main_f32", C.c_int32), ("passes_shared", C.c_int64)]
 
 
 class RrtxError(RuntimeError):

@@ -60,7 +60,7 @@ struct Inst {  // persistent per-instance state (global memory)
   int32_t first_goal;   // lowest index of a node lying exactly on the goal (-1 none yet, -2 unknown); f32-mirror path only
   int32_t goal_dups;    // nodes with a higher index lying exactly on the goal too, while first_goal >= 0
   int64_t iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes, alg_bytes,
-      exact_rescans, alg_bytes2, nu_max, f32_fallbacks, q16_fallbacks;
+      exact_rescans, alg_bytes2, nu_max, f32_fallbacks, q16_fallbacks, rides;
   int64_t phase[16];  // shader-clock cycles per phase as lane 0 sees them (filled by -DRRTX_PHASE_TIMERS builds only)
 };
 
@@ -104,6 +104,8 @@ struct Ctx {
   // elen[i] = hypot(node i - its parent), exactly the value calc_new_cost (rrt_04:1375-1377) would compute now;
   // kept by the v2 kernel so cost propagation needs no coordinates and no hypot
   double* elen;
+  // two iterations per streaming pass in the one-wave shape of the rrt_04 iteration kernel (rrt_star_v2_body.inc)
+  int32_t spec2;
 };
 
 // 16-bit mirror entry of a point (Ctx::xq)
@@ -1398,7 +1400,7 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
   I->sobol.lastq[0] = I->sobol.lastq[1] = I->sobol.lastq[2] = 0;
   I->iterations = I->edges_unique = I->edges_ref = I->near_hits = I->near_unique = 0;
   I->rewires = I->propagated = I->scan_nodes = I->alg_bytes = I->exact_rescans = I->alg_bytes2 = 0;
-  I->nu_max = I->f32_fallbacks = I->q16_fallbacks = 0;
+  I->nu_max = I->f32_fallbacks = I->q16_fallbacks = I->rides = 0;
   for (int k = 0; k < 16; k++) I->phase[k] = 0;
   c.results[inst].path_cost = 0.0;
   c.results[inst].n_nodes = 1;
@@ -1408,15 +1410,15 @@ __global__ void rrt_root_kernel(Ctx c, int ninst) {
 // Counters of a plan summed over the instances on the device (rrtx_stats): the host reads one 304-byte record instead of
 // copying every Inst back (2.7 KB each: 44 MB for 16 384 instances, 10+ ms of pageable-memory copy per plan).
 struct StatsAcc {
-  long long sum[14];     // iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes,
-                         // alg_bytes, exact_rescans, alg_bytes2, n, f32_fallbacks, q16_fallbacks
+  long long sum[15];     // iterations, edges_unique, edges_ref, near_hits, near_unique, rewires, propagated, scan_nodes,
+                         // alg_bytes, exact_rescans, alg_bytes2, n, f32_fallbacks, q16_fallbacks, rides
   long long nu_max;
   int32_t status_or, pad_;
   long long phase[16];
 };
 __global__ void stats_reduce_kernel(const Inst* inst, int ninst, StatsAcc* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  long long v[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nm = 0, ph[16];
+  long long v[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, nm = 0, ph[16];
   int st = 0;
 #pragma unroll
   for (int k = 0; k < 16; k++) ph[k] = 0;
@@ -1424,7 +1426,7 @@ __global__ void stats_reduce_kernel(const Inst* inst, int ninst, StatsAcc* out) 
     const Inst& I = inst[i];
     v[0] = I.iterations; v[1] = I.edges_unique; v[2] = I.edges_ref; v[3] = I.near_hits; v[4] = I.near_unique;
     v[5] = I.rewires; v[6] = I.propagated; v[7] = I.scan_nodes; v[8] = I.alg_bytes; v[9] = I.exact_rescans;
-    v[10] = I.alg_bytes2; v[11] = I.n; v[12] = I.f32_fallbacks; v[13] = I.q16_fallbacks;
+    v[10] = I.alg_bytes2; v[11] = I.n; v[12] = I.f32_fallbacks; v[13] = I.q16_fallbacks; v[14] = I.rides;
     nm = I.nu_max;
     st = I.status;
 #pragma unroll
@@ -1432,7 +1434,7 @@ __global__ void stats_reduce_kernel(const Inst* inst, int ninst, StatsAcc* out) 
   }
   // wave sums first (64 instances per atomic)
 #pragma unroll
-  for (int k = 0; k < 14; k++) {
+  for (int k = 0; k < 15; k++) {
     long long t = v[k];
     for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
     if ((threadIdx.x & 63) == 0 && t) atomicAdd((unsigned long long*)&out->sum[k], (unsigned long long)t);

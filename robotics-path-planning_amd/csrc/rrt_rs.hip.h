@@ -42,9 +42,13 @@ constexpr int RS_ST_RAISES = 32;   // include/rrtx.h RRTX_ST_REF_RAISES
 #ifdef RRTX_PHASE_TIMERS
 #define RS_T0 int64_t rt_ = (int64_t)__builtin_amdgcn_s_memtime();
 #define RS_T(k) do { if (threadIdx.x == 0) { int64_t t_ = (int64_t)__builtin_amdgcn_s_memtime(); sh.ph[k] += t_ - rt_; rt_ = t_; } } while (0)
+#define RS_M0 int64_t mt_ = (int64_t)__builtin_amdgcn_s_memtime();
+#define RS_M(k) do { if (threadIdx.x == 0) { int64_t t_ = (int64_t)__builtin_amdgcn_s_memtime(); sh.ph[k] += t_ - mt_; mt_ = t_; } } while (0)
 #else
 #define RS_T0
 #define RS_T(k) do { } while (0)
+#define RS_M0
+#define RS_M(k) do { } while (0)
 #endif
 
 struct ShR {
@@ -308,8 +312,10 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     __syncthreads();
   };
 
+  RS_M0
   for (int step = 0; step < iters && it < c.max_iter && !stop; step++, it++) {
     s_iter++;
+    RS_M(13);
     // ---------------- get_random_node :1658-1666
     if (lane == 0) {
       sh.rx = rpp::mt_uniform(&sh.rng, c.rand_min, c.rand_max);
@@ -318,6 +324,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     }
     __syncthreads();
     const double rx = sh.rx, ry = sh.ry, ryaw = sh.ryaw;
+    RS_M(4);
     // ---------------- get_nearest_node_index :1728-1734 (x, y only; first minimum)
     // The reference's distance is dx**2 + dy**2 with libm pow (rpp::py_d2); correctly rounded squares
     // (rpp::fast_d2) are within 2^-51 relative of it, so they decide everything except near-ties: the exact form is
@@ -371,11 +378,13 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     }
     wave_argmin(bd, ni);
     s_sn += n;
+    RS_M(5);
     // ---------------- steer :1541 + check_collision :1543
     int coll = 0, np0 = 0;
     const int ok0 = rs_edge(da, m, sh, x[ni], y[ni], yaw[ni], rx, ry, ryaw, pool_x + pool_used, pool_y + pool_used,
                             pool_w + pool_used, da.pool_cap - pool_used, &coll, &np0);
     if (fatal(ok0)) break;
+    RS_M(6);
     s_e += ok0 ? 1 : 0;   // collision-checked edges (check_collision calls on a node), as the oracle counts them
     s_pts += ok0 ? np0 : 0;
     int nnear = -1;
@@ -431,6 +440,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
       s_nh += k;
       nnear = k;
       __syncthreads();
+      RS_M(7);
       // `dist_list.index(d)` :1861: an entry names the FIRST node at that distance (it is itself in the list)
       for (int base = 0; base < k; base += TPB) {
         const int p = base + lane;
@@ -445,6 +455,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
         if (p < k) near[p] = v;   // near[q], q <= p: entries before p are already final or equal to their raw value
         __syncthreads();
       }
+      RS_M(8);
       // ---------------- choose_parent :1772-1813
       // The reference steers from EVERY near node and keeps the cheapest collision-free one (first in list order
       // among equal costs).  The cost of a candidate (:1901: parent cost + Euclidean distance) does not depend on
@@ -506,6 +517,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
         }
       }
       if (stop) break;
+      RS_M(9);
       truthy = (k > 0 && min_cost != rpp::dinf());
       if (truthy) {
         if (n + 2 > (int)c.stride) {
@@ -571,6 +583,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
             pool_used += rn;
             s_rw++;
             // propagate_cost_to_leaves :1905-1911, level by level below node i
+            RS_M(10);
             for (int j = lane; j < n; j += TPB) mark[j] = 0;
             __syncthreads();
             if (lane == 0) mark[i] = 1;
@@ -595,9 +608,11 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
                 break;
               }
             }
+            RS_M(11);
           }
         }
         if (stop) break;
+        RS_M(10);
         // ---------------- try_goal_path :1572-1582
         int gc = 0, gn = 0;
         const int gk = rs_edge(da, m, sh, x[me], y[me], yaw[me], gx, gy, gyaw, pool_x + pool_used,
@@ -606,6 +621,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
         s_e += gk ? 1 : 0;
         s_pts += gk ? gn : 0;
         if (gk && !gc) append_node(me, cost[me] + sh.cost_len, gn);
+        RS_M(12);
       }
     }
     if (inst == c.trace_inst && lane == 0) {
@@ -667,7 +683,7 @@ __global__ __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RS_WAVES, R
     c.results[inst].n_nodes = n;
     c.results[inst].status = I->status;
 #ifdef RRTX_PHASE_TIMERS
-    for (int k = 0; k < 4; k++) I->phase[k] += sh.ph[k];   // 0 variants, 1 select, 2 course, 3 points
+    for (int k = 0; k < 15; k++) I->phase[k] += sh.ph[k];   // 0 variants, 1 select, 2 course, 3 points; 4.. main-loop stages
     I->phase[15] += (int64_t)__builtin_amdgcn_s_memtime() - tk0_;   // whole kernel
 #endif
   }

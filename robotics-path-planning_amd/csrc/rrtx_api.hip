@@ -631,6 +631,8 @@ int rrtx_plan_begin(rrtx_handle* h) {
     if (atoi(e) == 0 && c.algo == RRTX_ALGO_INFORMED) c.xf = c.yf = nullptr;   // informed kernel: f64 passes only
   if (const char* e = getenv("RRTX_Q16"))
     if (atoi(e) == 0) c.xq = nullptr;   // rrt_04 kernel: no 16-bit first stage (f32 mirror first)
+  c.spec2 = 1;   // rrt_04 kernel, one-wave shape: two iterations per streaming pass (RRTX_SPEC2=0: one pass per iteration)
+  if (const char* e = getenv("RRTX_SPEC2")) c.spec2 = atoi(e) != 0;
   // The staged per-instance start state (RNG, start / goal) lives on the device too: uploaded when the host changed it,
   // copied device -> device at every plan (2.7 KB per instance: 44 MB of pageable-memory upload per plan of 16 384 instances)
   if (!h->d_inst0) {
@@ -1098,6 +1100,7 @@ static int plan_finish(rrtx_handle* h) {
   s.total_nodes = acc.sum[11];
   s.f32_fallbacks = acc.sum[12];
   s.q16_fallbacks = acc.sum[13];
+  s.passes_shared = acc.sum[14];
   s.near_unique_max = acc.nu_max;
   for (int k = 0; k < 16; k++) h->phase[k] = acc.phase[k];
   const bool overflow = (acc.status_or & RRTX_ST_OVERFLOW) != 0, unsupported = (acc.status_or & RRTX_ST_UNSUPPORTED) != 0,

@@ -177,6 +177,7 @@ def test_gpu_c2_full_size_equals_oracle(gpu, monkeypatch):
     for k in ("edges_ref", "edges_unique", "near_hits", "near_unique", "rewires", "propagated", "iterations"):
         assert out["stats"][k] == r["stats"][k], k
     assert out["stats"]["q16_fallbacks"] > 0      # the 16-bit stage ran (and handed some queries down)
+    assert out["stats"]["passes_shared"] > 30000  # ... and a third or more of the iterations rode on the pass before them
 
 
 def _orc_c2(a):
@@ -241,17 +242,22 @@ def test_gpu_c2_full_size_kernel_variants_agree(gpu, monkeypatch):
     kw = util.c2_kwargs(105000)
     seeds = [2, 3, 4]
     base = None
-    for tpb, f32 in (("256", "0"), ("256", "1"), ("128", "1"), ("64", "1"), ("64", "0")):
+    for tpb, f32, spec2 in (("256", "0", "1"), ("256", "1", "1"), ("128", "1", "1"), ("64", "1", "1"), ("64", "1", "0"),
+                            ("64", "0", "1")):
         monkeypatch.setenv("RRTX_TPB", tpb)
         monkeypatch.setenv("RRTX_F32", f32)
+        monkeypatch.setenv("RRTX_SPEC2", spec2)   # 64-thread shape: two iterations per streaming pass / one
         out = util.run_gpu_batch(kw, seeds)
+        # every second iteration of a dense tree rides on the pass before it -- and only in that configuration
+        rides = out["stats"]["passes_shared"]
+        assert (rides > 0.3 * out["stats"]["iterations"]) if (tpb, f32, spec2) == ("64", "1", "1") else rides == 0
         sig = [tuple(np.ascontiguousarray(a).tobytes() for a in t) for t in out["trees"]]
         paths = [None if p is None else np.asarray(p).tobytes() for p in out["paths"]]
         if base is None:
             base = (sig, paths, out["stats"]["rewires"], out["stats"]["propagated"])
         else:
-            assert sig == base[0] and paths == base[1], (tpb, f32)
-            assert (out["stats"]["rewires"], out["stats"]["propagated"]) == base[2:], (tpb, f32)
+            assert sig == base[0] and paths == base[1], (tpb, f32, spec2)
+            assert (out["stats"]["rewires"], out["stats"]["propagated"]) == base[2:], (tpb, f32, spec2)
 
 
 def test_size_independent_invariants(gpu):

@@ -24,9 +24,15 @@ s = h.get_stats()
 ph = h.get_phase_cycles()
 names = {0: "steer: 48 word variants", 1: "steer: set_path + arg-min", 2: "steer: course layout",
          3: "steer: points + collision + store"}
+main = {4: "sample", 5: "nearest scans", 6: "extension edge", 7: "near scans (2 stages)", 8: ".index collapse",
+        9: "choose_parent (costs, arg-min, edges)", 10: "rewire (search + edges)", 11: "propagate", 12: "try_goal_path edge",
+        13: "loop glue / trace / early test"}
 tot = float(ph[15])
 print("instances", B, "max_iter", it, "kernel_ms", s["kernel_ms"])
 for k in sorted(names):
     print("  %-36s %6.2f%%  %.0f ticks/edge call" % (names[k], 100.0 * ph[k] / tot if tot else 0, ph[k] / max(s["edges_unique"], 1)))
-print("  %-36s %6.2f%%" % ("everything else", 100.0 * (tot - ph[:4].sum()) / tot if tot else 0))
+print(" main loop (the steer stages above are inside these):")
+for k in sorted(main):
+    print("  %-40s %6.2f%%  %.0f ticks/iteration" % (main[k], 100.0 * ph[k] / tot if tot else 0, ph[k] / max(s["iterations"], 1)))
+print("  %-40s %6.2f%%" % ("outside the loop", 100.0 * (tot - ph[4:14].sum()) / tot if tot else 0))
 print({k: s[k] for k in ("iterations", "edges_unique", "near_hits", "rewires", "propagated", "total_nodes")})
