@@ -51,9 +51,10 @@ RPP_HD static inline void rs_ct(char* ct, const char* w) {
 //   6 left_x_right_left_x_right :1170 7 left_x_right90_straight_left :1189
 //   8 left_x_right90_straight_right :1205   9 left_straight_right90_x_left :1218
 //   10 left_straight_left90_x_right :1234   11 left_x_right90_straight_left90_x_right :1247
-RPP_HD static inline int rs_word(int w, double x, double y, double phi, double* d, char* ct, int* n, int* err) {
+// (sp, cp) = sin / cos of phi: handed in by the cooperative device path, which evaluates them once per steer)
+RPP_HD static inline int rs_word_sc(int w, double x, double y, double phi, double sp, double cp, double* d, char* ct,
+                                    int* n, int* err) {
   const double hp = kPi / 2;
-  const double sp = rpp_glibc_sin(phi), cp = rpp_glibc_cos(phi);
   const bool plus = (w == 1 || w == 5 || w == 6 || w == 8 || w == 10 || w == 11);   // words built on (x + sin, y - 1 - cos)
   const double zeta = plus ? x + sp : x - sp;
   const double eeta = plus ? y - 1.0 - cp : y - 1.0 + cp;
@@ -158,6 +159,9 @@ RPP_HD static inline int rs_word(int w, double x, double y, double phi, double* 
       return 0;
   }
 }
+RPP_HD static inline int rs_word(int w, double x, double y, double phi, double* d, char* ct, int* n, int* err) {
+  return rs_word_sc(w, x, y, phi, rpp_glibc_sin(phi), rpp_glibc_cos(phi), d, ct, n, err);
+}
 RPP_HD static inline double rs_sum_abs(const double* d, int n) {
   double s = 0;
   for (int i = 0; i < n; i++) s += dabs(d[i]);
@@ -179,16 +183,24 @@ RPP_HD static inline void rs_seg_trig(char mode, double oyaw, double* cs, double
   *cs = c0;
   *sn = (mode == 'S') ? s0 : -s0;
 }
-RPP_HD static inline void rs_delta(double dist, char mode, double maxc, double cs, double sn, double* dx, double* dy) {
+// (sd, cd) = sin / cos of dist (unused for straight segments)
+RPP_HD static inline void rs_delta_sc(double dist, char mode, double maxc, double cs, double sn, double sd, double cd,
+                                      double* dx, double* dy) {
   if (mode == 'S') {
     *dx = dist / maxc * cs;
     *dy = dist / maxc * sn;
   } else {
-    const double ldx = rpp_glibc_sin(dist) / maxc;
-    const double ldy = (mode == 'L') ? (1.0 - rpp_glibc_cos(dist)) / maxc : (1.0 - rpp_glibc_cos(dist)) / -maxc;
+    const double ldx = sd / maxc;
+    const double ldy = (mode == 'L') ? (1.0 - cd) / maxc : (1.0 - cd) / -maxc;
     *dx = cs * ldx + sn * ldy;
     *dy = -sn * ldx + cs * ldy;
   }
+}
+RPP_HD static inline void rs_delta(double dist, char mode, double maxc, double cs, double sn, double* dx, double* dy) {
+  if (mode == 'S')
+    rs_delta_sc(dist, mode, maxc, cs, sn, 0.0, 0.0, dx, dy);
+  else
+    rs_delta_sc(dist, mode, maxc, cs, sn, rpp_glibc_sin(dist), rpp_glibc_cos(dist), dx, dy);
 }
 RPP_HD static inline double rs_yaw_after(double dist, char mode, double oyaw) {
   return (mode == 'S') ? oyaw : ((mode == 'L') ? oyaw + dist : oyaw - dist);
@@ -209,26 +221,37 @@ struct RsFrame {
   double x, y, dth, step;
   double c, s;   // cos / sin of the start yaw
 };
-RPP_HD static inline void rs_frame(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
-                                   double step_size, RsFrame* F) {
+// (c, s) = cos / sin of the start yaw
+RPP_HD static inline void rs_frame_sc(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
+                                      double step_size, double c, double s, RsFrame* F) {
   const double dx = gx - sx, dy = gy - sy;
   F->dth = gyaw - syaw;
-  const double c = rpp_glibc_cos(syaw), s = rpp_glibc_sin(syaw);
   F->x = (c * dx + s * dy) * maxc;
   F->y = (-s * dx + c * dy) * maxc;
   F->c = c;
   F->s = s;
   F->step = step_size * maxc;
 }
+RPP_HD static inline void rs_frame(double sx, double sy, double syaw, double gx, double gy, double gyaw, double maxc,
+                                   double step_size, RsFrame* F) {
+  rs_frame_sc(sx, sy, syaw, gx, gy, gyaw, maxc, step_size, rpp_glibc_cos(syaw), rpp_glibc_sin(syaw), F);
+}
 // One (word family w, symmetry var) of generate_path :1298-1340.  Returns 0: no path from this variant, 1: a path
 // (d, ct, n filled, flips applied), 2: "Step size too large" (the reference returns [] there and then, :1071-1074),
 // < 0: the reference raises.
+// (sdth, cdth) = sin / cos of F.dth; the variants with phi = -dth take -sin, cos (the replicas are odd / even bit for
+// bit: tests/native/core_host_check.cpp)
+RPP_HD static inline int rs_variant_sc(int w, int var, const RsFrame& F, double sdth, double cdth, double* d, char* ct, int* n);
 RPP_HD static inline int rs_variant(int w, int var, const RsFrame& F, double* d, char* ct, int* n) {
+  return rs_variant_sc(w, var, F, rpp_glibc_sin(F.dth), rpp_glibc_cos(F.dth), d, ct, n);
+}
+RPP_HD static inline int rs_variant_sc(int w, int var, const RsFrame& F, double sdth, double cdth, double* d, char* ct, int* n) {
   const double xx = (var == 1 || var == 3) ? -F.x : F.x, yy = (var >= 2) ? -F.y : F.y;
-  const double pp = (var == 1 || var == 2) ? -F.dth : F.dth;
+  const bool neg = (var == 1 || var == 2);
+  const double pp = neg ? -F.dth : F.dth;
   int err = 0;
   *n = 0;
-  if (!rs_word(w, xx, yy, pp, d, ct, n, &err)) return err ? err : 0;
+  if (!rs_word_sc(w, xx, yy, pp, neg ? -sdth : sdth, cdth, d, ct, n, &err)) return err ? err : 0;
   const double tot = rs_sum_abs(d, *n);
   for (int i = 0; i < *n; i++)
     if (0.1 * tot < dabs(d[i]) && dabs(d[i]) < F.step) return 2;

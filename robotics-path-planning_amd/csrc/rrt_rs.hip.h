@@ -94,9 +94,17 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
   uint32_t code = 0;
   rpp::RsFrame F;
   F.c = F.s = 0.0;
+  // the four libm calls every variant starts with -- cos | sin of the start yaw (the frame, :1286-1296), sin | cos of the
+  // yaw difference (the words' phi) -- do not depend on each other: four lanes, one call each, at the same time
+  double t4 = 0.0;
+  if (lane < 4) {
+    const double arg = lane < 2 ? fyaw : tyaw - fyaw;
+    t4 = (lane == 0 || lane == 3) ? rpp_glibc_cos(arg) : rpp_glibc_sin(arg);
+  }
+  const double c_sy = __shfl(t4, 0), s_sy = __shfl(t4, 1), s_dth = __shfl(t4, 2), c_dth = __shfl(t4, 3);
   if (lane < 48) {
-    rpp::rs_frame(fx, fy, fyaw, tx, ty, tyaw, da.curvature, da.step_size, &F);
-    st = rpp::rs_variant(lane >> 2, lane & 3, F, sh.vd[lane], sh.vct[lane], &nn);
+    rpp::rs_frame_sc(fx, fy, fyaw, tx, ty, tyaw, da.curvature, da.step_size, c_sy, s_sy, &F);
+    st = rpp::rs_variant_sc(lane >> 2, lane & 3, F, s_dth, c_dth, sh.vd[lane], sh.vct[lane], &nn);
     if (st == 1) {
       L = rpp::rs_sum_abs(sh.vd[lane], nn);
       code = rpp::rs_code(sh.vct[lane]);
@@ -136,28 +144,41 @@ __device__ __noinline__ int rs_edge(const DubArgs& da, int m, ShR& sh, double fx
   // ---- generate_local_course :1355-1377 laid out for random access: one lane per segment, then a short chain
   const int nl = sh.vn[sel];
   rpp::RsCourse& C = sh.course;
-  if (lane < nl) {
-    double oyaw = 0.0;
-    for (int q = 0; q < lane; q++) oyaw = rpp::rs_yaw_after(sh.vd[sel][q], sh.vct[sel][q], oyaw);
-    const double len = sh.vd[sel][lane];
-    const char md = sh.vct[sel][lane];
-    const double ds = da.step_size * da.curvature;
-    const double d_dist = len >= 0.0 ? ds : -ds;
-    const double q = (len - 0.0) / d_dist;            // np.arange(0.0, length, d_dist)
-    const long cnt = (q > 0.0) ? (long)__builtin_ceil(q) : 0;
-    double cs, sn, dx, dy;
-    rpp::rs_seg_trig(md, oyaw, &cs, &sn);
-    rpp::rs_delta(len, md, da.curvature, cs, sn, &dx, &dy);
-    C.len[lane] = len;
-    C.ddist[lane] = d_dist;
-    C.ct[lane] = md;
-    C.oyaw[lane] = oyaw;
-    C.cs[lane] = cs;
-    C.sn[lane] = sn;
-    C.cnt[lane] = (int32_t)cnt;
-    sh.sdx[lane] = dx;
-    sh.sdy[lane] = dy;
-  } else if (lane == 8) {
+  // four lanes per segment: cos | sin of its origin yaw, sin | cos of its length -- the four calls of rs_seg_trig /
+  // rs_delta at once instead of one after the other on the segment's lane; lane 4 * s then lays segment s out
+  {
+    const int sg = lane >> 2, wh = lane & 3;
+    double oyaw = 0.0, len = 0.0, tv = 0.0;
+    char md = 'S';
+    if (sg < nl) {
+      for (int q = 0; q < sg; q++) oyaw = rpp::rs_yaw_after(sh.vd[sel][q], sh.vct[sel][q], oyaw);
+      len = sh.vd[sel][sg];
+      md = sh.vct[sel][sg];
+      const double arg = wh < 2 ? oyaw : len;
+      tv = (wh == 0 || wh == 3) ? rpp_glibc_cos(arg) : rpp_glibc_sin(arg);
+    }
+    const int b4 = lane & ~3;
+    const double c0 = __shfl(tv, b4), s0 = __shfl(tv, b4 + 1), sd = __shfl(tv, b4 + 2), cd = __shfl(tv, b4 + 3);
+    if (sg < nl && wh == 0) {
+      const double ds = da.step_size * da.curvature;
+      const double d_dist = len >= 0.0 ? ds : -ds;
+      const double q = (len - 0.0) / d_dist;            // np.arange(0.0, length, d_dist)
+      const long cnt = (q > 0.0) ? (long)__builtin_ceil(q) : 0;
+      const double cs = c0, sn = (md == 'S') ? s0 : -s0;   // rs_seg_trig
+      double dx, dy;
+      rpp::rs_delta_sc(len, md, da.curvature, cs, sn, sd, cd, &dx, &dy);
+      C.len[sg] = len;
+      C.ddist[sg] = d_dist;
+      C.ct[sg] = md;
+      C.oyaw[sg] = oyaw;
+      C.cs[sg] = cs;
+      C.sn[sg] = sn;
+      C.cnt[sg] = (int32_t)cnt;
+      sh.sdx[sg] = dx;
+      sh.sdy[sg] = dy;
+    }
+  }
+  if (lane == 32) {
     C.cg = F.c;     // cos(-syaw), sin(-syaw) of :1411-1417 from the frame's cos / sin(syaw) (even / odd bit for bit)
     C.sg = -F.s;
     C.sx = fx;
