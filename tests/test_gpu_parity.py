@@ -424,6 +424,39 @@ def test_gpu_plans_resume_across_kernel_launches(gpu, monkeypatch):
         assert np.array_equal(out["paths"][0], g["path"][:, :2]) and np.array_equal(out["path_yaws"][0], g["path"][:, 2])
 
 
+@pytest.mark.parametrize("chunk", [None, "300", "97"])
+def test_gpu_one_wave_shape_with_shared_passes_matches_the_goldens(gpu, monkeypatch, chunk):
+    """The kernel shape the bench times (64 threads per instance, 16-bit stage) answers the near query of every second
+    iteration from the streaming pass of the iteration before: samples are drawn two ahead, so the RNG /
+    Sobol state handed back, the per-iteration trace and the counters are the sensitive outputs.  Every rrt_04 golden that
+    keeps planning to max_iter, as one launch and as launches of 300 / 97 iterations (the look-ahead must stop at a launch's
+    end); with RRTX_SPEC2=0 (one pass per iteration) the same trees."""
+    monkeypatch.setenv("RRTX_TPB", "64")
+    if chunk:
+        monkeypatch.setenv("RRTX_CHUNK_ITERS", chunk)
+    rode = 0
+    for path in util.golden_files("rrt04_c2") + util.golden_files("rrt04_drv"):
+        g = util.load_golden(path)
+        kw = util.kwargs_from_golden(g)
+        if not kw.get("search_until_max_iter", True):
+            continue
+        out = util.run_gpu_batch(kw, [int(g["seed"])], trace_instance=0)
+        d = util.first_trace_divergence(out["trace"], g["tr_rnd_x"], g["tr_rnd_y"], g["tr_nearest"])
+        assert d is None, "%s: first divergent iteration %d" % (g["name"], d)
+        _check_against_golden(g, out)
+        assert out["stats"]["edges_ref"] == int(g["ref_edges"]), g["name"]
+        if kw["sobol"]:
+            assert out["sobol_index"][0] == int(g["sobol_index_after"])
+        rode += out["stats"]["passes_shared"]
+    assert rode > 0
+    if chunk is None:
+        monkeypatch.setenv("RRTX_SPEC2", "0")
+        g = util.load_golden(util.GOLDEN + "/rrt04_c2_s1_it4000.npz")
+        out = util.run_gpu_batch(util.kwargs_from_golden(g), [int(g["seed"])])
+        _check_against_golden(g, out)
+        assert out["stats"]["passes_shared"] == 0
+
+
 def test_informed_host_class_drop_in(gpu):
     import random
     import rrt_amd

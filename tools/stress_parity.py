@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Stress parity (GPU box): many seeds per planner, GPU trees vs the golden-pinned oracle, bit for bit.
 Usage: python tools/stress_parity.py [count]   (default 256 seeds per configuration; STRESS_ONLY=rrt06 / STRESS_ONLY=moved run that block only,
-STRESS_ONLY=pose the rrt_05 / rrt_03 / rrt_07 blocks, STRESS_ONLY=rrt07 the rrt_07 blocks)"""
+STRESS_ONLY=pose the rrt_05 / rrt_03 / rrt_07 blocks, STRESS_ONLY=rrt07 the rrt_07 blocks, STRESS_ONLY=rrt04 the rrt_04 iteration kernel in
+the 64-thread shape and the automatic one)"""
 import os
 import sys
 from concurrent.futures import ProcessPoolExecutor
@@ -96,6 +97,43 @@ if __name__ == "__main__":
     total = 0
     with ProcessPoolExecutor(max_workers=14) as ex:
         seeds = list(range(1, CNT + 1))
+        if os.environ.get("STRESS_ONLY") == "rrt04":
+            # the rrt_04 iteration kernel in the shape the bench times (64 threads per instance: 16-bit stage, two iterations
+            # per streaming pass, libm-free extension / candidate edges) and in the shape a small batch gets by itself
+            for tpb in ("64", ""):
+                if tpb:
+                    os.environ["RRTX_TPB"] = tpb
+                else:
+                    os.environ.pop("RRTX_TPB", None)
+                tag = "[%s threads] " % (tpb or "auto")
+                for sob in (0, 1):
+                    kw = util.c2_kwargs(4000); kw["sobol"] = sob
+                    out = util.run_gpu_batch(kw, seeds)
+                    total += compare(tag + "rrt_04 C2 map, 4000 it, sobol=%d (shared %d)" % (sob, out["stats"]["passes_shared"]),
+                                     out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
+                kw = util.c2_kwargs(12000)
+                out = util.run_gpu_batch(kw, seeds[:max(CNT // 4, 16)])
+                total += compare(tag + "rrt_04 C2 map, 12000 it", out["trees"], list(ex.map(o04, [(s, kw) for s in seeds[:max(CNT // 4, 16)]])))
+                kw = util.kwargs_from_golden(util.load_golden(util.GOLDEN + "/rrt04_drv_mt_s1234.npz")); kw["max_iter"] = 2000
+                out = util.run_gpu_batch(kw, seeds)
+                total += compare(tag + "rrt_04 driver map, 2000 it", out["trees"], list(ex.map(o04, [(s, kw) for s in seeds])))
+                # a dense small map: extensions snap from a few hundred nodes on, goal rate 20
+                kwd = dict(util.C2)
+                kwd.update(start=[1, 1], goal=[18, 18], rand_area=[0, 20], obstacles=[(6, 6, 2), (12, 9, 2.5), (8, 15, 1.5), (15, 15, 1)],
+                           expand_dis=1.0, path_resolution=0.25, goal_sample_rate=20, connect_circle_dist=50.0, max_iter=5000,
+                           robot_radius=0.0)
+                out = util.run_gpu_batch(kwd, seeds)
+                total += compare(tag + "rrt_04 dense 20 x 20 map, 5000 it (shared %d)" % out["stats"]["passes_shared"], out["trees"],
+                                 list(ex.map(o04, [(s, kwd) for s in seeds])))
+                for res, rate, it in ((0.05, 95, 400), (0.05, 20, 400), (0.1, 60, 400), (0.3, 95, 600)):
+                    kwm = dict(util.C2)
+                    kwm.update(start=[0, 0], goal=[6, 8], rand_area=[-2, 12], obstacles=[(3, 3, 1)], expand_dis=3.0,
+                               path_resolution=res, goal_sample_rate=rate, connect_circle_dist=50.0, max_iter=it, robot_radius=0.0)
+                    out = util.run_gpu_batch(kwm, seeds)
+                    total += compare(tag + "rrt_04 moved nodes res %g rate %d (replanned %d)" % (res, rate, out["stats"]["replanned"]),
+                                     out["trees"], list(ex.map(o04x, [(s, kwm) for s in seeds])))
+            print("TOTAL mismatches", total)
+            sys.exit(1 if total else 0)
         # rrt_06 (lazy candidate order on the device vs the oracle steering every candidate)
         rs_cases = (("driver, 750 it", {}), ("driver, 2000 it", {"max_iter": 2000}),
                     ("driver, early exit", {"search_until_max_iter": 0, "max_iter": 1500}),
