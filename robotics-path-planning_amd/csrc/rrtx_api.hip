@@ -631,8 +631,10 @@ int rrtx_plan_begin(rrtx_handle* h) {
     if (atoi(e) == 0 && c.algo == RRTX_ALGO_INFORMED) c.xf = c.yf = nullptr;   // informed kernel: f64 passes only
   if (const char* e = getenv("RRTX_Q16"))
     if (atoi(e) == 0) c.xq = nullptr;   // rrt_04 kernel: no 16-bit first stage (f32 mirror first)
-  c.spec2 = 1;   // rrt_04 kernel, one-wave shape: two iterations per streaming pass (RRTX_SPEC2=0: one pass per iteration)
-  if (const char* e = getenv("RRTX_SPEC2")) c.spec2 = atoi(e) != 0;
+  // rrt_04 kernel, one-wave shape: a streaming pass serves up to 1 + spec2 iterations (clamped to the kernel's RRT2_SPECK;
+  // RRTX_SPEC2=0: one pass per iteration)
+  c.spec2 = 8;
+  if (const char* e = getenv("RRTX_SPEC2")) c.spec2 = atoi(e) > 0 ? atoi(e) : 0;
   // The staged per-instance start state (RNG, start / goal) lives on the device too: uploaded when the host changed it,
   // copied device -> device at every plan (2.7 KB per instance: 44 MB of pageable-memory upload per plan of 16 384 instances)
   if (!h->d_inst0) {

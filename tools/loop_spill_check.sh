@@ -26,7 +26,7 @@ groups.append(cur)
 i=0
 while i<len(groups):
     g=groups[i]
-    if len(g)>=4:
+    if len(g)>=2:
         j=i+1; last=g[-1]
         while j<len(groups) and len(groups[j])==1: last=groups[j][0]; j+=1
         if j>i+1:
