@@ -141,8 +141,9 @@ typedef struct rrtx_stats {
                                 obstacle count, the estimated near-set size and RRTX_TPB); the other planners' fixed shape */
   int32_t main_f32;          /* RRTX_ALGO_RRT_STAR iteration kernel: 1 = f32-mirror instantiation (<true>), 0 = f64 passes */
   int64_t passes_shared;     /* RRTX_ALGO_RRT_STAR iteration kernel, 64-thread shape: iterations whose near query was answered
-                                by the streaming pass of the iteration before (the ball speculated about the sample, on which
-                                steer() snaps the new node once the tree is dense): no pass of their own, 0 bytes of xq[] */
+                                by the streaming pass of an earlier iteration (the ball speculated about the sample, on which
+                                steer() snaps the new node once the tree is dense; up to three iterations ride on one pass):
+                                no pass of their own, 0 bytes of xq[] */
 } rrtx_stats;
 
 typedef struct rrtx_handle rrtx_handle;
