@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-end measurement set (GPU box):  gpurun -- 'RRTX_COMMIT=<short hash> bash tools/measure_round.sh'
+# Round-end measurement set (GPU box):  gpurun --timeout 1200 -- 'RRTX_COMMIT=<short hash> bash tools/measure_round.sh a'   then   '... b'
+# (two calls: one call may run 1 200 s at most.  a = C2: profile passes, the driver's command, phase splits; b = the other workloads)
 # (the box has no .git: the hash of the commit being measured is handed in; do not edit the tree while the call is queued --
 # the snapshot is taken when the call starts)
 #   1. rocprofv3 passes of the headline bench: --kernel-trace --stats, --pmc FETCH_SIZE, --pmc WRITE_SIZE (separate passes)
@@ -14,6 +15,8 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 O=$REPO/gpurun_out/r3
 mkdir -p $O
 cd $REPO
+PART=${1:-ab}
+if [[ $PART == *a* ]]; then
 SUMMARY_ARGS="--workload c2" bash tools/profile_headline.sh r3_c2 > $O/profile_headline.log 2>&1
 cp profiles/r3_c2_* $O/ 2>/dev/null
 tail -2 $O/profile_headline.log
@@ -26,6 +29,11 @@ echo "phase rc=$?"
 RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c3.py 1024 20000 > $O/r3_c3_phase.txt 2>&1
 RRTX_LIB=robotics-path-planning_amd/librrtx_prof.so timeout -k 10 120 python3 tools/phase_profile_c5.py 1536 5000 > $O/r3_c5_phase.txt 2>&1
 echo "phase c3/c5 rc=$?"
+timeout -k 10 200 python3 bench.py --instances 8192 --warmup 1 --steps 1 --no-cpu-baseline > $O/r3_bench_c2_8192.json 2> $O/bench_c2_8192.err
+RRTX_SPEC2=0 timeout -k 10 200 python3 bench.py --warmup 1 --steps 2 --no-cpu-baseline > $O/r3_bench_c2_one_pass_per_iteration.json 2> $O/bench_c2_spec0.err
+echo "extra c2 benches rc=$?"
+fi
+if [[ $PART == *b* ]]; then
 # C3 (rrt_07): kernel stats + HBM traffic passes of its own (profiles/r3_c3_kernel_stats.csv, r3_c3_traffic.json)
 SUMMARY_ARGS="--workload c3 --kernel-match rrt_informed_kernel --instances 1024 --max-iter 20000 --obstacles 200 --variant q16_mirror" bash tools/profile_headline.sh r3_c3 --workload c3 > $O/profile_headline_c3.log 2>&1
 cp profiles/r3_c3_* $O/ 2>/dev/null
@@ -40,7 +48,6 @@ echo "cpu fullsize rc=$?"
 # C4 at 16 384 instances (work queue, longest expected run first; 5 walled-in starts end RRTX_ST_REF_HANGS) and C2 at 8 192
 timeout -k 10 150 python3 bench.py --workload c4 --instances 16384 --warmup 1 --steps 5 --no-cpu-baseline > $O/r3_bench_c4_16384.json 2> $O/bench_c4_16384.err
 RRTX_BITSTAR_FIFO=1 timeout -k 10 150 python3 bench.py --workload c4 --instances 16384 --warmup 1 --steps 5 --no-cpu-baseline > $O/r3_bench_c4_16384_fifo.json 2> $O/bench_c4_16384_fifo.err
-timeout -k 10 200 python3 bench.py --instances 8192 --warmup 1 --steps 1 --no-cpu-baseline > $O/r3_bench_c2_8192.json 2> $O/bench_c2_8192.err
 echo "extra benches rc=$?"
 for w in c3 c4 c5 c6; do
   bash tools/valu_pass.sh $w > $O/valu_$w.log 2>&1
@@ -50,6 +57,7 @@ for w in c3 c4 c5 c6; do
   echo "bench $w rc=$?"
 done
 timeout -k 10 120 tools/ubench/lat_ubench > $O/r3_lat_ubench.txt 2>&1
+fi
 python3 - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/r3/r3_bench_*.json")):
