@@ -558,7 +558,12 @@ def main():
             tj = json.load(open(tfile))
             tc = tj["config"]
             if tc["instances_per_gpu"] == wl.B and tc["max_iter"] == wl.max_iter and tc["obstacles"] == wl.M:
-                if tj.get("csrc_hash") == csrc_hash(a.workload):
+                knobs = [k for k in ("RRTX_SPEC2", "RRTX_Q16", "RRTX_F32", "RRTX_TPB", "RRTX_KERNEL") if os.environ.get(k) is not None]
+                if knobs:
+                    # the PMC passes ran the default configuration: another pass structure moves other bytes
+                    roof["traffic_note"] = "profiles/%s belongs to the default configuration (%s set here): not used" % (
+                        os.path.basename(tfile), ", ".join(knobs))
+                elif tj.get("csrc_hash") == csrc_hash(a.workload):
                     roof["traffic"] = tj["hbm_bytes_per_launch"]
                     roof["traffic_per_step"] = tj["hbm_bytes_per_step"]
                     t_gbps = tj["hbm_bytes_per_step"] / 1e9 / (kms / 1e3 / sd)
