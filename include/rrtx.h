@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RRTX_ABI_VERSION 4   /* 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
+#define RRTX_ABI_VERSION 5   /* 5: rrtx_stats.passes_shared; 2: rrtx_params.step_size, RRTX_ALGO_RS, rrtx_get_path_yaw; 3: RRTX_PARTIAL,
                                 rrtx_copy_results_device, per-instance yaw and informed rotation; 4: rrtx_plan_many,
                                 rrtx_selfcheck, rrtx_stats.main_shape / main_f32, rrtx_plan_begin / _step, rrtx_set_launch_bound,
                                 RRTX_ST_REF_HANGS, rrtx_rccl_* */

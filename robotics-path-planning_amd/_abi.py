@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRTX_LIB") or os.path.join(_HERE, "librrtx.so")
 
-RRTX_ABI_VERSION = 4
+RRTX_ABI_VERSION = 5
 ALGO_RRT, ALGO_RRT_STAR, ALGO_INFORMED, ALGO_DUBINS, ALGO_BITSTAR, ALGO_RRT_DUBINS, ALGO_RS = 0, 1, 2, 3, 4, 5, 6
 SAMPLER_MT, SAMPLER_SOBOL = 0, 1
 ST_DONE, ST_PATH, ST_OVERFLOW, ST_PATH_TRUNC, ST_UNSUPPORTED, ST_REF_RAISES, ST_REF_HANGS = 1, 2, 4, 8, 16, 32, 64
