@@ -540,13 +540,13 @@ def main():
                         "the handle's stream, measured in this run"}
         ls0 = state["last_stats"]
         if a.workload == "c2" and ls0.get("passes_shared") and ls0.get("iterations"):
-            # iterations whose near query was answered by the streaming pass of the iteration before:
+            # iterations whose near query was answered by the streaming pass of an earlier iteration:
             # they move no mirror bytes, so the algorithmic bytes above are those of the passes that did run
             roof["passes_shared_frac"] = ls0["passes_shared"] / ls0["iterations"]
-            roof["passes_shared_note"] = ("the pass of iteration i also answers the near ball of iteration i+1 (speculated about its "
-                                          "sample) and the nearest query of sample i+2: that share of the iterations ran without a "
-                                          "pass of their own; RRTX_SPEC2=0 runs one pass per iteration (twice the bytes, a higher "
-                                          "fraction of the HBM peak, a lower edge rate: DESIGN.md 6.0)")
+            roof["passes_shared_note"] = ("the pass of iteration i also answers the near balls of iterations i+1 .. i+3 (speculated "
+                                          "about their samples) and the nearest queries of the samples after them: that share of the "
+                                          "iterations ran without a pass of their own; RRTX_SPEC2=0 runs one pass per iteration (three "
+                                          "times the bytes, a higher fraction of the HBM peak, a lower edge rate: DESIGN.md 6.0)")
         if achieved_2s:
             roof["survey_8d_two_scan_equivalent_GBps"] = achieved_2s
             roof["survey_8d_two_scan_note"] = ("SURVEY 8(d)'s two-f64-scan formula (32*n + 48*k + 24*M + 28 per "
